@@ -1,0 +1,19 @@
+// ctx.h -- the opaque goai_ctx: one GPU, one board size, one stream, plus the device
+// buffers of the network and of the per-game search trees.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+
+struct goai_ctx {
+    int device = 0;
+    int S = 0, P = 0, A = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;   // everything hipMalloc'ed on behalf of this context
+
+    void release()
+    {
+        for (void* p : allocs) (void)hipFree(p);
+        allocs.clear();
+    }
+};

@@ -1,0 +1,48 @@
+// goai_internal.h -- shared host-side declarations of libgoai_hip.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/goai_hip.h"
+
+namespace goai {
+
+void set_error(const std::string& msg);
+
+#define GOAI_HIP_CHECK(expr)                                                                  \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ::goai::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));             \
+            return GOAI_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+#define GOAI_REQUIRE(cond, msg)                                                               \
+    do {                                                                                      \
+        if (!(cond)) { ::goai::set_error(msg); return GOAI_ERR_ARG; }                         \
+    } while (0)
+
+inline bool size_supported(int s) { return s == 5 || s == 7 || s == 9 || s == 13 || s == 19; }
+
+// Dispatch a templated launcher on the board size.
+#define GOAI_DISPATCH_SIZE(S_RT, ...)                                                         \
+    switch (S_RT) {                                                                           \
+        case 5: { constexpr int S = 5; __VA_ARGS__; } break;                                  \
+        case 7: { constexpr int S = 7; __VA_ARGS__; } break;                                  \
+        case 9: { constexpr int S = 9; __VA_ARGS__; } break;                                  \
+        case 13: { constexpr int S = 13; __VA_ARGS__; } break;                                \
+        case 19: { constexpr int S = 19; __VA_ARGS__; } break;                                \
+        default: ::goai::set_error("unsupported board size"); return GOAI_ERR_ARG;            \
+    }
+
+// ---- Go rule kernels (go_kernels.hip) ----
+int launch_transition(int S, const uint8_t* states, const int32_t* actions, int canonical, uint8_t* out,
+                      int32_t* status, int n, hipStream_t st);
+int launch_children(int S, const uint8_t* states, int canonical, uint8_t* children, uint8_t* valid,
+                    int8_t* win, int n, hipStream_t st);
+int launch_score(int S, const uint8_t* states, int32_t* black_area, int32_t* white_area, int32_t* ended,
+                 int32_t* winner, int n, hipStream_t st);
+
+}  // namespace goai

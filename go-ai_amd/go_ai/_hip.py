@@ -1,0 +1,72 @@
+"""ctypes binding of libgoai_hip.so (include/goai_hip.h).
+
+This is the only place the package touches the native library.  PyTorch-ROCm is used for
+device memory and streams only: tensors are handed over as raw `data_ptr()`s.  There is no
+CPU fallback: if the library is missing the import of this module raises.
+"""
+import ctypes
+import os
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_DIR, "libgoai_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make -C go-ai_amd/csrc` (or __graft_entry__.build()); "
+        "this package has no CPU fallback")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+c_void_p, c_int, c_int64, c_uint64, c_float, c_double = (
+    ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_double)
+
+lib.goai_last_error.restype = ctypes.c_char_p
+lib.goai_last_error.argtypes = []
+lib.goai_version.restype = c_int
+lib.goai_version.argtypes = []
+
+_SIGNATURES = {
+    "goai_ctx_create": [ctypes.POINTER(c_void_p), c_int, c_int],
+    "goai_ctx_destroy": [c_void_p],
+    "goai_ctx_set_stream": [c_void_p, c_void_p],
+    "goai_ctx_sync": [c_void_p],
+    "goai_transition": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int],
+    "goai_children": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int],
+    "goai_score": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int],
+    "goai_nn_init": [c_void_p, c_int, c_int, c_int, c_int],
+    "goai_load_weights": [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), c_int],
+    "goai_nn_forward": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int],
+    "goai_mcts_init": [c_void_p, c_int, c_int, c_int],
+    "goai_mcts_reset": [c_void_p, c_void_p],
+    "goai_mcts_select": [c_void_p, c_void_p],
+    "goai_mcts_backup": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "goai_mcts_run": [c_void_p, c_int],
+    "goai_mcts_readout": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "goai_mcts_policy": [c_void_p, c_double, c_void_p],
+    "goai_sample_actions": [c_void_p, c_void_p, c_uint64, c_uint64, c_void_p],
+    "goai_mcts_advance": [c_void_p, c_void_p],
+    "goai_mcts_counters": [c_void_p, ctypes.POINTER(c_int64)],
+}
+
+for _name, _args in _SIGNATURES.items():
+    if hasattr(lib, _name):
+        _fn = getattr(lib, _name)
+        _fn.restype = c_int
+        _fn.argtypes = _args
+
+
+class GoaiError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise GoaiError(f"libgoai_hip error {rc}: {lib.goai_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "libgoai_hip takes contiguous device tensors"
+    return c_void_p(t.data_ptr())

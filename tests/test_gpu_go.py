@@ -1,0 +1,89 @@
+"""GPU parity of the Go-rule kernels against the CPU oracle, through the C ABI (bit-exact)."""
+import numpy as np
+import pytest
+
+from helpers import from_ascii, random_positions
+from oracle.gogame import GoGame
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    from go_ai.engine import Context
+    cache = {}
+
+    def get(size):
+        if size not in cache:
+            cache[size] = Context(size)
+        return cache[size]
+    yield get
+    for c in cache.values():
+        c.close()
+
+
+def _random_actions(states, rng, illegal_frac=0.1):
+    acts = []
+    for st in states:
+        valid = GoGame.valid_moves(st)
+        if rng.random() < illegal_frac and valid.min() == 0:
+            acts.append(int(rng.choice(np.flatnonzero(valid == 0))))
+        else:
+            acts.append(int(rng.choice(np.flatnonzero(valid))))
+    return np.asarray(acts, dtype=np.int32)
+
+
+@pytest.mark.parametrize("size,n", [(5, 600), (7, 300), (9, 1500), (13, 400), (19, 200)])
+def test_transition_matches_oracle(ctxs, size, n):
+    rng = np.random.default_rng(size)
+    states = random_positions(size, n, seed=size, max_moves=int(1.3 * size * size), canonical=False)
+    acts = _random_actions(states, rng)
+    for canonical in (True, False):
+        want, wstatus = GoGame.next_states_u8(states, acts, canonical=canonical)
+        got, gstatus = ctxs(size).transition(states, acts, canonical=canonical)
+        got, gstatus = got.cpu().numpy(), gstatus.cpu().numpy()
+        assert np.array_equal(gstatus != 0, wstatus != 0)
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("size,n", [(5, 64), (9, 96), (13, 16), (19, 6)])
+def test_children_valid_win_match_oracle(ctxs, size, n):
+    states = random_positions(size, n, seed=10 + size, max_moves=int(1.2 * size * size), canonical=True,
+                              pass_prob=0.15)
+    kids, valid, win = [t.cpu().numpy() for t in ctxs(size).children(states, canonical=True)]
+    for i, st in enumerate(states):
+        wk, wv = GoGame.children_u8(st, canonical=True)
+        assert np.array_equal(valid[i], wv)
+        assert np.array_equal(valid[i].astype(np.float64), GoGame.valid_moves(st))
+        assert np.array_equal(kids[i], wk)
+        wwin = [GoGame.winning(c) if GoGame.game_ended(c) else 0 for c in wk]
+        assert np.array_equal(win[i], np.asarray(wwin, dtype=np.int8))
+
+
+@pytest.mark.parametrize("size,n", [(5, 300), (9, 600), (19, 100)])
+def test_score_matches_oracle(ctxs, size, n):
+    states = random_positions(size, n, seed=20 + size, max_moves=2 * size * size, canonical=False, pass_prob=0.05)
+    b, w, ended, winner = [t.cpu().numpy() for t in ctxs(size).score(states)]
+    for i, st in enumerate(states):
+        assert (b[i], w[i]) == GoGame.areas(st)
+        assert ended[i] == GoGame.game_ended(st)
+        assert winner[i] == GoGame.winning(st)
+
+
+def test_edge_cases(ctxs):
+    c = ctxs(5)
+    # n = 0 is a no-op
+    out, status = c.transition(np.zeros((0, 6, 5, 5), np.uint8), np.zeros(0, np.int32))
+    assert out.shape[0] == 0
+    # ko, capture and pass-pass known answers (same positions as tests/test_oracle_go.py)
+    st = from_ascii([".XO..", "XO.O.", ".XO..", ".....", "....."], to_move=0).astype(np.uint8)
+    out, status = c.transition(st[None], np.asarray([7], np.int32), canonical=False)
+    out = out.cpu().numpy()[0]
+    assert status.item() == 0 and out[3, 1, 1] == 1 and out[1, 1, 1] == 0 and out[2].min() == 1
+    p1, _ = c.transition(st[None], np.asarray([25], np.int32), canonical=True)
+    p2, _ = c.transition(p1, np.asarray([25], np.int32), canonical=True)
+    assert p1.cpu().numpy()[0, 4].min() == 1 and p1.cpu().numpy()[0, 5].max() == 0
+    assert p2.cpu().numpy()[0, 5].min() == 1
+    # out-of-range and occupied actions are rejected with a zero state
+    out, status = c.transition(st[None].repeat(2, 0), np.asarray([26, 1], np.int32))
+    assert (status.cpu().numpy() != 0).all() and out.cpu().numpy().max() == 0
