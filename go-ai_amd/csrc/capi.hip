@@ -94,4 +94,32 @@ int goai_score(goai_ctx* ctx, const uint8_t* states, int32_t* black_area, int32_
     return launch_score(ctx->S, states, black_area, white_area, ended, winner, n, ctx->stream);
 }
 
+int goai_nn_init(goai_ctx* ctx, int net_kind, int n_blocks, int max_batch, int dtype)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(dtype == GOAI_DTYPE_F32, "only GOAI_DTYPE_F32 is implemented");
+    return nn_init(ctx, net_kind, n_blocks, max_batch);
+}
+
+int goai_load_weights(goai_ctx* ctx, const char* const* names, const float* const* tensors_host,
+                      const int64_t* numels, int n_tensors)
+{
+    CTX_ENTER(ctx);
+    return nn_load_weights(ctx, names, tensors_host, numels, n_tensors);
+}
+
+int goai_nn_forward(goai_ctx* ctx, const uint8_t* states, float* pi_logits, float* val_logits, int n, int mode)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(n >= 0, "n < 0");
+    GOAI_REQUIRE(mode == GOAI_NN_RAW || mode == GOAI_NN_NUMPY_SHIM, "unknown mode");
+    if (n == 0) return GOAI_OK;
+    GOAI_REQUIRE(states && val_logits, "NULL array argument");
+    GOAI_REQUIRE(ctx->net.kind == 0 || pi_logits == nullptr, "the value net has no policy head");
+    int rc = nn_forward_raw(ctx, states, pi_logits, val_logits, n);
+    if (rc) return rc;
+    if (mode == GOAI_NN_NUMPY_SHIM) rc = launch_numpy_shim(ctx->S, states, pi_logits, val_logits, n, ctx->stream);
+    return rc;
+}
+
 }  // extern "C"

@@ -5,11 +5,14 @@
 #include <stdint.h>
 #include <vector>
 
+#include "nn.h"
+
 struct goai_ctx {
     int device = 0;
     int S = 0, P = 0, A = 0;
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;   // everything hipMalloc'ed on behalf of this context
+    goai::Net net;
 
     void release()
     {

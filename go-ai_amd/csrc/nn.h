@@ -1,0 +1,42 @@
+// nn.h -- device-side weight images of the policy/value CNN and its launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace goai {
+
+struct HeadWeights {
+    const float* conv_w;       // [3][128]: act ch0, act ch1, crit (BN folded); value net uses slot 2 only
+    const float* conv_b;       // [3]
+    const float* act_lin_wt;   // [2P][A]  (transposed Linear weight), AC only
+    const float* act_lin_b;    // [A]
+    const float* crit_w1t;     // [P][256]
+    const float* crit_b1;      // [256]
+    const float* crit_w2;      // [256]
+    const float* crit_b2;      // [1]
+};
+
+struct Net {
+    int kind = -1;             // 0 actor-critic, 1 value
+    int layers = 0;            // residual blocks (reference: 3)
+    int max_batch = 0;
+    bool loaded = false;
+    float shift = 0.0f;        // input shift: 0.5 for the AC net (ac_net.py:41), 0 for the value net
+    float* w0 = nullptr;       // [54][128]   conv0, k = ci*9 + tap
+    float* b0 = nullptr;       // [128]
+    float* wt = nullptr;       // [2*layers][4 chunks][9 taps][128 out][32 in]
+    float* bt = nullptr;       // [2*layers][128]
+    float* head_blob = nullptr;
+    HeadWeights hw{};
+    float* act[3] = { nullptr, nullptr, nullptr };   // activation buffers [max_batch*P][128]
+};
+
+int launch_conv0(int S, const uint8_t* states, const float* w0, const float* b0, float shift, float* out,
+                 int nboards, hipStream_t st);
+int launch_conv3x3(int S, const float* in, const float* wt, const float* bias, const float* resid, float* out, int M,
+                   hipStream_t st);
+int launch_heads(int S, const float* act, const HeadWeights& hw, int is_ac, float* pi, float* val, int nboards,
+                 hipStream_t st);
+int launch_numpy_shim(int S, const uint8_t* states, float* pi, float* val, int n, hipStream_t st);
+
+}  // namespace goai

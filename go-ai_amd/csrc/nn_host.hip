@@ -1,0 +1,199 @@
+// nn_host.hip -- host side of the CNN: buffer set-up, state_dict ingestion with BatchNorm
+// folding and weight re-layout, and the per-batch launch sequence.
+//
+// Weight names are the reference's own state_dict keys:
+//   main.0 / main.1                      conv0 + BN      (/root/reference/go_ai/models/__init__.py:22-26)
+//   main.{3+i}.main.{0,1,3,4}            BasicBlock i    (/root/reference/go_ai/models/__init__.py:234-251)
+//   act_head.{0,1,4}, crit_head.{0,1,4,6}  AC heads      (/root/reference/go_ai/models/ac_net.py:15-31)
+//   convs.{0,1,4,6}                       value head     (/root/reference/go_ai/models/val_net.py:12-20)
+// game_head.* and *.num_batches_tracked are ignored.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ctx.h"
+#include "goai_internal.h"
+
+namespace goai {
+
+static int dev_alloc(goai_ctx* c, void** p, size_t bytes)
+{
+    GOAI_HIP_CHECK(hipMalloc(p, bytes));
+    c->allocs.push_back(*p);
+    return GOAI_OK;
+}
+
+int nn_init(goai_ctx* c, int kind, int layers, int max_batch)
+{
+    GOAI_REQUIRE(kind == 0 || kind == 1, "net_kind must be 0 (actor-critic) or 1 (value)");
+    GOAI_REQUIRE(layers >= 0 && layers <= 64, "n_blocks out of range");
+    GOAI_REQUIRE(max_batch > 0, "max_batch must be positive");
+    GOAI_REQUIRE(c->net.kind < 0, "goai_nn_init was already called on this context");
+    Net& n = c->net;
+    n.kind = kind;
+    n.layers = layers;
+    n.max_batch = max_batch;
+    n.shift = kind == 0 ? 0.5f : 0.0f;
+    int rc;
+    if ((rc = dev_alloc(c, (void**)&n.w0, 54 * 128 * sizeof(float)))) return rc;
+    if ((rc = dev_alloc(c, (void**)&n.b0, 128 * sizeof(float)))) return rc;
+    if (layers > 0) {
+        if ((rc = dev_alloc(c, (void**)&n.wt, (size_t)2 * layers * 9 * 128 * 128 * sizeof(float)))) return rc;
+        if ((rc = dev_alloc(c, (void**)&n.bt, (size_t)2 * layers * 128 * sizeof(float)))) return rc;
+    }
+    const size_t P = c->P, A = c->A;
+    const size_t head_floats = 3 * 128 + 4 + 2 * P * A + A + P * 256 + 256 + 256 + 4;
+    if ((rc = dev_alloc(c, (void**)&n.head_blob, head_floats * sizeof(float)))) return rc;
+    for (int i = 0; i < 3; i++)
+        if ((rc = dev_alloc(c, (void**)&n.act[i], (size_t)max_batch * P * 128 * sizeof(float)))) return rc;
+    return GOAI_OK;
+}
+
+namespace {
+struct Tensor { const float* p; int64_t n; };
+typedef std::map<std::string, Tensor> TensorMap;
+
+bool get(const TensorMap& m, const std::string& k, int64_t numel, const float*& out)
+{
+    auto it = m.find(k);
+    if (it == m.end()) { set_error("state_dict is missing " + k); return false; }
+    if (it->second.n != numel) {
+        set_error("state_dict tensor " + k + " has " + std::to_string(it->second.n) + " elements, expected " +
+                  std::to_string(numel));
+        return false;
+    }
+    out = it->second.p;
+    return true;
+}
+
+// scale[c] = gamma / sqrt(var + eps), shift[c] = (conv_bias - mean) * scale + beta
+bool bn_fold(const TensorMap& m, const std::string& conv, const std::string& bn, int C, std::vector<double>& scale,
+             std::vector<double>& shift)
+{
+    const float *cb, *g, *b, *mu, *var;
+    if (!get(m, conv + ".bias", C, cb) || !get(m, bn + ".weight", C, g) || !get(m, bn + ".bias", C, b) ||
+        !get(m, bn + ".running_mean", C, mu) || !get(m, bn + ".running_var", C, var))
+        return false;
+    scale.resize(C);
+    shift.resize(C);
+    for (int c = 0; c < C; c++) {
+        scale[c] = (double)g[c] / std::sqrt((double)var[c] + 1e-5);
+        shift[c] = ((double)cb[c] - (double)mu[c]) * scale[c] + (double)b[c];
+    }
+    return true;
+}
+}  // namespace
+
+int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* tensors, const int64_t* numels, int n)
+{
+    Net& net = c->net;
+    GOAI_REQUIRE(net.kind >= 0, "call goai_nn_init first");
+    GOAI_REQUIRE(names && tensors && numels && n > 0, "NULL / empty weight table");
+    TensorMap m;
+    for (int i = 0; i < n; i++) {
+        GOAI_REQUIRE(names[i] && tensors[i], "NULL entry in weight table");
+        m[names[i]] = Tensor{ tensors[i], numels[i] };
+    }
+    const int P = c->P, A = c->A;
+    std::vector<double> sc, sh;
+    const float* w;
+
+    // conv0 -> [k = ci*9 + tap][cout]
+    std::vector<float> w0(54 * 128), b0(128);
+    if (!get(m, "main.0.weight", 128 * 6 * 9, w) || !bn_fold(m, "main.0", "main.1", 128, sc, sh)) return GOAI_ERR_ARG;
+    for (int co = 0; co < 128; co++) {
+        for (int k = 0; k < 54; k++) w0[k * 128 + co] = (float)((double)w[co * 54 + k] * sc[co]);
+        b0[co] = (float)sh[co];
+    }
+    GOAI_HIP_CHECK(hipMemcpy(net.w0, w0.data(), w0.size() * sizeof(float), hipMemcpyHostToDevice));
+    GOAI_HIP_CHECK(hipMemcpy(net.b0, b0.data(), b0.size() * sizeof(float), hipMemcpyHostToDevice));
+
+    // trunk convs -> [conv][chunk][tap][cout][32 cin]
+    std::vector<float> wt((size_t)9 * 128 * 128), bt(128);
+    for (int l = 0; l < 2 * net.layers; l++) {
+        const std::string base = "main." + std::to_string(3 + l / 2) + ".main.";
+        const std::string conv = base + (l % 2 ? "3" : "0"), bn = base + (l % 2 ? "4" : "1");
+        if (!get(m, conv + ".weight", 128 * 128 * 9, w) || !bn_fold(m, conv, bn, 128, sc, sh)) return GOAI_ERR_ARG;
+        for (int chunk = 0; chunk < 4; chunk++)
+            for (int tap = 0; tap < 9; tap++)
+                for (int co = 0; co < 128; co++)
+                    for (int k = 0; k < 32; k++) {
+                        int ci = chunk * 32 + k;
+                        wt[(((size_t)chunk * 9 + tap) * 128 + co) * 32 + k] =
+                            (float)((double)w[((size_t)co * 128 + ci) * 9 + tap] * sc[co]);
+                    }
+        for (int co = 0; co < 128; co++) bt[co] = (float)sh[co];
+        GOAI_HIP_CHECK(hipMemcpy(net.wt + (size_t)l * 9 * 128 * 128, wt.data(), wt.size() * sizeof(float),
+                                 hipMemcpyHostToDevice));
+        GOAI_HIP_CHECK(hipMemcpy(net.bt + (size_t)l * 128, bt.data(), 128 * sizeof(float), hipMemcpyHostToDevice));
+    }
+
+    // heads
+    const size_t o_conv_w = 0, o_conv_b = 3 * 128, o_alw = o_conv_b + 4, o_alb = o_alw + (size_t)2 * P * A,
+                 o_w1 = o_alb + A, o_b1 = o_w1 + (size_t)P * 256, o_w2 = o_b1 + 256, o_b2 = o_w2 + 256;
+    std::vector<float> blob(o_b2 + 4, 0.0f);
+    const std::string crit = net.kind == 0 ? "crit_head" : "convs";
+    if (net.kind == 0) {
+        if (!get(m, "act_head.0.weight", 2 * 128, w) || !bn_fold(m, "act_head.0", "act_head.1", 2, sc, sh))
+            return GOAI_ERR_ARG;
+        for (int ch = 0; ch < 2; ch++) {
+            for (int k = 0; k < 128; k++) blob[o_conv_w + ch * 128 + k] = (float)((double)w[ch * 128 + k] * sc[ch]);
+            blob[o_conv_b + ch] = (float)sh[ch];
+        }
+        const float* lb;
+        if (!get(m, "act_head.4.weight", (int64_t)A * 2 * P, w) || !get(m, "act_head.4.bias", A, lb)) return GOAI_ERR_ARG;
+        for (int a = 0; a < A; a++) {
+            for (int j = 0; j < 2 * P; j++) blob[o_alw + (size_t)j * A + a] = w[(size_t)a * 2 * P + j];
+            blob[o_alb + a] = lb[a];
+        }
+    }
+    if (!get(m, crit + ".0.weight", 128, w) || !bn_fold(m, crit + ".0", crit + ".1", 1, sc, sh)) return GOAI_ERR_ARG;
+    for (int k = 0; k < 128; k++) blob[o_conv_w + 2 * 128 + k] = (float)((double)w[k] * sc[0]);
+    blob[o_conv_b + 2] = (float)sh[0];
+    const float *l1b, *l2w, *l2b;
+    if (!get(m, crit + ".4.weight", (int64_t)256 * P, w) || !get(m, crit + ".4.bias", 256, l1b) ||
+        !get(m, crit + ".6.weight", 256, l2w) || !get(m, crit + ".6.bias", 1, l2b))
+        return GOAI_ERR_ARG;
+    for (int o = 0; o < 256; o++) {
+        for (int p = 0; p < P; p++) blob[o_w1 + (size_t)p * 256 + o] = w[(size_t)o * P + p];
+        blob[o_b1 + o] = l1b[o];
+        blob[o_w2 + o] = l2w[o];
+    }
+    blob[o_b2] = l2b[0];
+    GOAI_HIP_CHECK(hipMemcpy(net.head_blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    const float* hb = net.head_blob;
+    net.hw = HeadWeights{ hb + o_conv_w, hb + o_conv_b, hb + o_alw, hb + o_alb, hb + o_w1, hb + o_b1, hb + o_w2, hb + o_b2 };
+    net.loaded = true;
+    return GOAI_OK;
+}
+
+// Raw network outputs for n states (pi may be NULL; always NULL-able for the value net).
+int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, int n)
+{
+    Net& net = c->net;
+    GOAI_REQUIRE(net.loaded, "weights not loaded (goai_load_weights)");
+    const int P = c->P, A = c->A;
+    for (int done = 0; done < n; done += net.max_batch) {
+        const int nb = (n - done) < net.max_batch ? (n - done) : net.max_batch;
+        const int M = nb * P;
+        int rc;
+        if ((rc = launch_conv0(c->S, states + (size_t)done * 6 * P, net.w0, net.b0, net.shift, net.act[0], nb, c->stream)))
+            return rc;
+        float *x = net.act[0], *y = net.act[1], *z = net.act[2];
+        for (int l = 0; l < net.layers; l++) {
+            const float* w1 = net.wt + (size_t)(2 * l) * 9 * 128 * 128;
+            const float* w2 = net.wt + (size_t)(2 * l + 1) * 9 * 128 * 128;
+            if ((rc = launch_conv3x3(c->S, x, w1, net.bt + (size_t)(2 * l) * 128, nullptr, y, M, c->stream))) return rc;
+            if ((rc = launch_conv3x3(c->S, y, w2, net.bt + (size_t)(2 * l + 1) * 128, x, z, M, c->stream))) return rc;
+            float* t = x; x = z; z = t;
+        }
+        if ((rc = launch_heads(c->S, x, net.hw, net.kind == 0 && pi != nullptr, pi ? pi + (size_t)done * A : nullptr, val + done, nb,
+                               c->stream)))
+            return rc;
+    }
+    return GOAI_OK;
+}
+
+}  // namespace goai

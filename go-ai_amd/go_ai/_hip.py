@@ -34,7 +34,7 @@ _SIGNATURES = {
     "goai_children": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int],
     "goai_score": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int],
     "goai_nn_init": [c_void_p, c_int, c_int, c_int, c_int],
-    "goai_load_weights": [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), c_int],
+    "goai_load_weights": [c_void_p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), c_int],
     "goai_nn_forward": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int],
     "goai_mcts_init": [c_void_p, c_int, c_int, c_int],
     "goai_mcts_reset": [c_void_p, c_void_p],

@@ -37,6 +37,7 @@ class Context:
         h = ctypes.c_void_p()
         _hip.check(_hip.lib.goai_ctx_create(ctypes.byref(h), self.device_index, self.size))
         self._h = h
+        self.net_kind = -1
         self.set_stream(torch.cuda.current_stream(self.device))
 
     def close(self):
@@ -85,3 +86,35 @@ class Context:
         outs = [torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(4)]
         _hip.check(_hip.lib.goai_score(self._h, _hip.ptr(st), *[_hip.ptr(o) for o in outs], n))
         return tuple(outs)   # black_area, white_area, ended, winner
+
+    # ---- CNN -----------------------------------------------------------------------
+    NET_AC, NET_VAL = 0, 1
+    NN_RAW, NN_NUMPY_SHIM = 0, 1
+
+    def nn_init(self, net_kind, n_blocks=3, max_batch=1024):
+        self.net_kind = int(net_kind)
+        _hip.check(_hip.lib.goai_nn_init(self._h, self.net_kind, int(n_blocks), int(max_batch), 0))
+
+    def load_weights(self, state_dict):
+        """state_dict: mapping of the reference's keys to float tensors / arrays (host)."""
+        names, arrays = [], []
+        for k, v in state_dict.items():
+            a = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+            if a.dtype.kind != "f":
+                continue                      # num_batches_tracked
+            names.append(k.encode())
+            arrays.append(np.ascontiguousarray(a, dtype=np.float32))
+        n = len(names)
+        c_names = (ctypes.c_char_p * n)(*names)
+        c_ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrays])
+        c_numels = (ctypes.c_int64 * n)(*[a.size for a in arrays])
+        _hip.check(_hip.lib.goai_load_weights(self._h, c_names, c_ptrs, c_numels, n))
+
+    def nn_forward(self, states, mode=0, want_pi=True):
+        st = _dev_u8_states(states, self.device)
+        n = st.shape[0]
+        want_pi = want_pi and self.net_kind == self.NET_AC
+        pi = torch.empty((n, self.A), dtype=torch.float32, device=self.device) if want_pi else None
+        val = torch.empty((n, 1), dtype=torch.float32, device=self.device)
+        _hip.check(_hip.lib.goai_nn_forward(self._h, _hip.ptr(st), _hip.ptr(pi), _hip.ptr(val), n, int(mode)))
+        return pi, val

@@ -77,6 +77,41 @@ int goai_children(goai_ctx* ctx, const uint8_t* states, int canonical, uint8_t* 
 int goai_score(goai_ctx* ctx, const uint8_t* states, int32_t* black_area, int32_t* white_area,
                int32_t* ended, int32_t* winner, int n);
 
+/* ---------------------------------------------------------------------------------------
+ * Policy / value CNN forward
+ * ------------------------------------------------------------------------------------- */
+#define GOAI_NET_AC 0       /* ActorCriticNet, /root/reference/go_ai/models/ac_net.py:8-64 */
+#define GOAI_NET_VAL 1      /* ValueNet,       /root/reference/go_ai/models/val_net.py:8-27 */
+#define GOAI_DTYPE_F32 0    /* fp32 storage, fp32 matrix-core accumulate (the reference's precision) */
+#define GOAI_NN_RAW 0       /* the nn.Module outputs (ac_net.forward / val_net.forward) */
+#define GOAI_NN_NUMPY_SHIM 1 /* + RLNet._numpy post-processing, models/__init__.py:90-105 */
+
+/* Allocate the network of this context: the reference trunk (conv3x3 6->128 + n_blocks
+ * BasicBlocks of 128 channels, /root/reference/go_ai/models/__init__.py:14-31; the
+ * reference hard-codes n_blocks = 3) with the heads of `net_kind`.  Forward calls are
+ * processed in slices of at most max_batch states. */
+int goai_nn_init(goai_ctx* ctx, int net_kind, int n_blocks, int max_batch, int dtype);
+
+/* Load a state_dict: `names[i]` are the reference's own keys ("main.0.weight",
+ * "main.3.main.1.running_var", "act_head.4.bias", "convs.6.weight", ...; what
+ * net.state_dict() / torch.load give, /root/reference/go_ai/policies/baselines.py:160-172),
+ * `tensors_host[i]` HOST pointers to contiguous float32 data of `numels[i]` elements.
+ * Unknown keys (game_head.*) are ignored, missing ones are an error.  BatchNorm running
+ * statistics are folded into the convolutions (the reference always evaluates in eval()
+ * mode, models/__init__.py:64).  Synchronous; the data is copied. */
+int goai_load_weights(goai_ctx* ctx, const char* const* names, const float* const* tensors_host,
+                      const int64_t* numels, int n_tensors);
+
+/* Network forward for n states: pi_logits [n][A] float32 (NULL for the value net or when
+ * only values are wanted), val_logits [n][1] float32.
+ * mode GOAI_NN_RAW        = pt_actor_critic / pt_critic (ac_net.py:40-64, val_net.py:22-27);
+ * mode GOAI_NN_NUMPY_SHIM = RLNet._numpy(states, 'actor_critic' | 'critic')
+ *   (/root/reference/go_ai/models/__init__.py:54-113): invalid moves get
+ *   np.finfo(float32).min, children that end the game get -100 * winning(child), finished
+ *   states get val = 100 * winning(state). */
+int goai_nn_forward(goai_ctx* ctx, const uint8_t* states, float* pi_logits, float* val_logits, int n,
+                    int mode);
+
 #ifdef __cplusplus
 }
 #endif

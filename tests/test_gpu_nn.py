@@ -1,0 +1,127 @@
+"""GPU parity of the CNN forward (HIP, fp32 matrix cores) through the C ABI.
+
+Tolerance (BASELINE.json north_star): 1e-3 relative error in fp32.  Measured as
+max|got - want| / max(|want|, 1) per output row, against (a) the golden outputs of the
+reference's real nn.Modules (tests/golden/nn_*.npz) and (b) the torch fp32 oracle
+(oracle/nn_ref.py) on larger seeded batches, including ragged batch sizes that leave the
+last MFMA tile partly empty and batches larger than the context's max_batch slice.
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load_nn
+from helpers import random_positions
+from oracle import nn_ref
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-3
+
+
+def rel_err(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1.0)))
+
+
+def make_ctx(kind, size, seed, layers=3, max_batch=256):
+    from go_ai.engine import Context
+    c = Context(size)
+    c.nn_init(Context.NET_AC if kind == "ac" else Context.NET_VAL, layers, max_batch)
+    sd = nn_ref.make_state_dict(kind, size, seed, layers)
+    c.load_weights(sd)
+    return c, sd
+
+
+@pytest.mark.parametrize("name", ["nn_ac5", "nn_ac9", "nn_val9"])
+def test_forward_matches_reference_golden(name):
+    g = load_nn(name)
+    kind, size, seed = str(g["kind"]), int(g["size"]), int(g["seed"])
+    c, sd = make_ctx(kind, size, seed)
+    assert nn_ref.state_dict_digest(sd) == str(g["digest"])
+    pi, val = c.nn_forward(g["states"], mode=c.NN_RAW)
+    assert rel_err(val.cpu().numpy(), g["val_raw"]) < REL_TOL
+    if kind == "ac":
+        assert rel_err(pi.cpu().numpy(), g["pi_raw"]) < REL_TOL
+    # RLNet._numpy semantics: masks and assist overrides are exact, the rest within tolerance
+    pi, val = c.nn_forward(g["states"], mode=c.NN_NUMPY_SHIM)
+    val = val.cpu().numpy()
+    special = np.isin(g["val_np"], (-100.0, 0.0, 100.0)) & (np.abs(g["val_raw"]) > 1e-6)
+    assert np.array_equal(val[special], g["val_np"][special])
+    assert rel_err(val, g["val_np"]) < REL_TOL
+    if kind == "ac":
+        pi = pi.cpu().numpy()
+        lowest = np.finfo(np.float32).min
+        assert np.array_equal(pi == lowest, g["pi_np"] == lowest)
+        ok = g["pi_np"] != lowest
+        assert rel_err(pi[ok], g["pi_np"][ok]) < REL_TOL
+    c.close()
+
+
+@pytest.mark.parametrize("kind,size,n,layers,max_batch", [
+    ("ac", 9, 333, 3, 128),     # ragged: 333*81 rows is not a multiple of the 128-row tile; 3 slices
+    ("ac", 5, 77, 3, 256),
+    ("val", 9, 200, 3, 256),
+    ("ac", 13, 50, 3, 64),
+    ("ac", 19, 24, 3, 32),
+    ("ac", 19, 9, 10, 16),      # "deeper CNN" of BASELINE.json configs[4]
+    ("ac", 9, 1, 3, 8),         # batch of one, as the reference evaluates
+    ("ac", 9, 40, 0, 64),       # no residual blocks: conv0 + heads only
+])
+def test_forward_matches_torch_oracle(kind, size, n, layers, max_batch):
+    c, sd = make_ctx(kind, size, 100 + size + layers, layers, max_batch)
+    states = random_positions(size, n, seed=size * 7 + n, canonical=True, pass_prob=0.05)
+    want_pi, want_val = nn_ref.forward(sd, torch.tensor(states), kind)
+    pi, val = c.nn_forward(states, mode=c.NN_RAW)
+    assert rel_err(val.cpu().numpy(), want_val.numpy()) < REL_TOL
+    if kind == "ac":
+        assert rel_err(pi.cpu().numpy(), want_pi.numpy()) < REL_TOL
+        # critic-only call on the AC net (pt_critic, ac_net.py:58-61)
+        _, val2 = c.nn_forward(states, mode=c.NN_RAW, want_pi=False)
+        assert np.array_equal(val2.cpu().numpy(), val.cpu().numpy())
+    # batch invariance: a state's outputs do not depend on its neighbours in the batch
+    k = min(n, 5)
+    pi_k, val_k = c.nn_forward(states[:k], mode=c.NN_RAW)
+    assert np.array_equal(val_k.cpu().numpy(), val.cpu().numpy()[:k])
+    c.close()
+
+
+def test_numpy_shim_matches_oracle_on_special_states():
+    from oracle.gogame import GoGame
+    c, sd = make_ctx("ac", 5, 11)
+    base = random_positions(5, 12, seed=77, min_moves=8, canonical=True, pass_prob=0.0)
+    sts = []
+    for st in base:
+        p1 = GoGame.next_state(st, 25, canonical=True)
+        p2 = GoGame.next_state(p1, 25, canonical=True)
+        sts += [st, p1.astype(np.uint8), p2.astype(np.uint8)]
+    sts = np.asarray(sts, dtype=np.uint8)
+    want_pi, want_val = nn_ref.numpy_shim(sd, "ac", "actor_critic", sts)
+    pi, val = c.nn_forward(sts, mode=c.NN_NUMPY_SHIM)
+    pi, val = pi.cpu().numpy(), val.cpu().numpy()
+    lowest = np.finfo(np.float32).min
+    assert np.array_equal(pi == lowest, want_pi == lowest)
+    ok = want_pi != lowest
+    assert rel_err(pi[ok], want_pi[ok]) < REL_TOL
+    ended = np.array([GoGame.game_ended(s) for s in sts], dtype=bool)
+    assert np.array_equal(val[ended], want_val[ended])
+    assert rel_err(val, want_val) < REL_TOL
+    c.close()
+
+
+def test_load_weights_errors():
+    from go_ai import _hip
+    from go_ai.engine import Context
+    c = Context(5)
+    with pytest.raises(_hip.GoaiError):
+        c.nn_forward(np.zeros((1, 6, 5, 5), np.uint8))          # nn_init not called / weights missing
+    c.nn_init(Context.NET_AC, 3, 8)
+    sd = nn_ref.make_state_dict("ac", 5, 1)
+    bad = dict(sd)
+    del bad["main.4.main.3.weight"]
+    with pytest.raises(_hip.GoaiError, match="missing"):
+        c.load_weights(bad)
+    bad = dict(sd)
+    bad["act_head.4.weight"] = bad["act_head.4.weight"][:, :-1]
+    with pytest.raises(_hip.GoaiError, match="elements"):
+        c.load_weights(bad)
+    c.close()
