@@ -122,4 +122,95 @@ int goai_nn_forward(goai_ctx* ctx, const uint8_t* states, float* pi_logits, floa
     return rc;
 }
 
+int goai_mcts_init(goai_ctx* ctx, int n_games, int max_sims, int mode)
+{
+    CTX_ENTER(ctx);
+    return mcts_init(ctx, n_games, max_sims, mode);
+}
+
+int goai_mcts_reset(goai_ctx* ctx, const uint8_t* root_states)
+{
+    CTX_ENTER(ctx);
+    return mcts_reset(ctx, root_states);
+}
+
+int goai_mcts_select(goai_ctx* ctx, uint8_t* leaf_states_out)
+{
+    CTX_ENTER(ctx);
+    return mcts_select(ctx, leaf_states_out);
+}
+
+int goai_mcts_backup(goai_ctx* ctx, const float* pi_logits, const float* prior, const float* val_logits,
+                     int logits_are_raw)
+{
+    CTX_ENTER(ctx);
+    return mcts_backup(ctx, pi_logits, prior, val_logits, logits_are_raw);
+}
+
+int goai_mcts_run(goai_ctx* ctx, int n_sims)
+{
+    CTX_ENTER(ctx);
+    return mcts_run(ctx, n_sims);
+}
+
+int goai_mcts_readout(goai_ctx* ctx, int32_t* visit_counts, double* prior, int32_t* root_visits)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(ctx->tree.steps_since_reset >= 0, "call goai_mcts_init and goai_mcts_reset first");
+    return launch_mcts_readout(ctx->S, ctx->tree, visit_counts, prior, root_visits, ctx->stream);
+}
+
+int goai_mcts_policy(goai_ctx* ctx, double temp, double* pi)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(ctx->tree.steps_since_reset >= 0, "call goai_mcts_init and goai_mcts_reset first");
+    GOAI_REQUIRE(pi != nullptr && temp > 0.0, "pi is NULL or temp <= 0");
+    return launch_mcts_policy(ctx->S, ctx->tree, temp, pi, ctx->stream);
+}
+
+int goai_uniform_policy(goai_ctx* ctx, int allow_pass, double* pi)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(ctx->tree.steps_since_reset >= 0, "call goai_mcts_init and goai_mcts_reset first");
+    GOAI_REQUIRE(pi != nullptr, "pi is NULL");
+    return launch_uniform_policy(ctx->S, ctx->tree, allow_pass, pi, ctx->stream);
+}
+
+int goai_sample_actions(goai_ctx* ctx, const double* pi, uint64_t seed, uint64_t step, int game_id_offset,
+                        int32_t* actions)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(ctx->tree.n_games > 0, "call goai_mcts_init first");
+    GOAI_REQUIRE(pi && actions, "NULL array argument");
+    return launch_sample(ctx->S, ctx->tree, pi, seed, step, game_id_offset, actions, ctx->stream);
+}
+
+int goai_mcts_advance(goai_ctx* ctx, const int32_t* actions)
+{
+    CTX_ENTER(ctx);
+    return mcts_advance(ctx, actions);
+}
+
+int goai_mcts_roots(goai_ctx* ctx, uint8_t* states, int32_t* turn, int32_t* moves, int32_t* result)
+{
+    CTX_ENTER(ctx);
+    const goai::Tree& t = ctx->tree;
+    GOAI_REQUIRE(t.steps_since_reset >= 0, "call goai_mcts_init and goai_mcts_reset first");
+    const size_t bytes = (size_t)t.n_games * sizeof(int32_t);
+    if (turn) GOAI_HIP_CHECK(hipMemcpyAsync(turn, t.turn, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (moves) GOAI_HIP_CHECK(hipMemcpyAsync(moves, t.moves, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (result) GOAI_HIP_CHECK(hipMemcpyAsync(result, t.result, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (states) return launch_mcts_roots(ctx->S, t, states, ctx->stream);
+    return GOAI_OK;
+}
+
+int goai_mcts_counters(goai_ctx* ctx, int64_t* counters_host)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(ctx->tree.n_games > 0 && counters_host, "call goai_mcts_init first / NULL output");
+    GOAI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    GOAI_HIP_CHECK(hipMemcpy(counters_host, ctx->tree.counters, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return GOAI_OK;
+}
+
 }  // extern "C"

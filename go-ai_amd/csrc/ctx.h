@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <vector>
 
+#include "mcts.h"
 #include "nn.h"
 
 struct goai_ctx {
@@ -13,6 +14,7 @@ struct goai_ctx {
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;   // everything hipMalloc'ed on behalf of this context
     goai::Net net;
+    goai::Tree tree;
 
     void release()
     {

@@ -304,7 +304,7 @@ __device__ __forceinline__ int planes_load(const uint8_t* in, uint64_t* me, uint
 {
     using G = Geom<S>;
     const int lane = lane_id();
-    uint64_t t = 0, pz = 0, dn = 0, c0[G::K], c1[G::K];
+    uint64_t t = 0, pz = 0, c0[G::K], c1[G::K];
     int ncell_done = 0;
 #pragma unroll
     for (int k = 0; k < G::K; k++) {
@@ -316,7 +316,6 @@ __device__ __forceinline__ int planes_load(const uint8_t* in, uint64_t* me, uint
         inv[k] = __ballot(in_b && in[3 * G::P + idx] != 0);
         pz |= __ballot(in_b && in[4 * G::P + idx] != 0);
         uint64_t d = __ballot(in_b && in[5 * G::P + idx] != 0);
-        dn |= d;
         ncell_done += __popcll(d);
     }
     int player = t ? 1 : 0;

@@ -50,4 +50,12 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch);
 int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* tensors, const int64_t* numels, int n);
 int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, int n);
 
+// ---- search (mcts_host.hip) ----
+int mcts_init(goai_ctx* c, int n_games, int max_sims, int mode);
+int mcts_reset(goai_ctx* c, const uint8_t* roots);
+int mcts_select(goai_ctx* c, uint8_t* leaf_states_out);
+int mcts_backup(goai_ctx* c, const float* pi_logits, const float* prior, const float* val, int raw);
+int mcts_run(goai_ctx* c, int n_sims);
+int mcts_advance(goai_ctx* c, const int32_t* actions);
+
 }  // namespace goai

@@ -1,0 +1,61 @@
+// mcts.h -- GPU-resident per-game search trees (struct-of-arrays over games x nodes).
+//
+// Replaces the Python object tree of /root/reference/go_ai/search/tree.py:22-52: every
+// tree.Node field becomes one array indexed [game][node]; the per-action data a parent
+// needs for PUCT (tree.py:170-184) is kept in rows indexed [game][node][action] so that a
+// wavefront reads them coalesced, one action per lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace goai {
+
+struct Tree {
+    int n_games = 0, max_sims = 0, ncap = 0, mode = 0;
+    int steps_since_reset = 0;
+    bool pending_select = false;
+    // nodes: [G][ncap]
+    uint64_t* st = nullptr;      // [..][SW] packed state: me[K], opp[K], inv[K], meta
+    int32_t* parent = nullptr;
+    int32_t* pact = nullptr;     // action that led here
+    int32_t* visits = nullptr;
+    double* accR = nullptr;      // [..][8] lane accumulators of numpy's pairwise sum over full blocks of 8
+    double* accT = nullptr;      // [..][8] pending tail (visits % 8 entries)
+    // rows: [G][ncap][A]
+    double* prior = nullptr;
+    int32_t* child = nullptr;
+    int32_t* cN = nullptr;       // child visit counts
+    double* cQ = nullptr;        // -mean(tanh(child.post_vals)), 0 while unvisited
+    // per game: [G]
+    int32_t* nnodes = nullptr;
+    int32_t* leaf = nullptr;
+    int32_t* depth = nullptr;
+    int32_t* path = nullptr;     // [G][ncap]
+    int32_t* turn = nullptr;     // absolute colour to move at the root (0 black, 1 white)
+    int32_t* moves = nullptr;    // moves played so far in the game
+    int32_t* result = nullptr;   // 2 = running, else black's result {-1,0,1} once finished
+    // NN hand-off
+    uint8_t* leaf_planes = nullptr;   // [G][6][P]
+    float* pi_logits = nullptr;       // [G][A]
+    float* val_logits = nullptr;      // [G]
+    double* sqrt_tab = nullptr;       // sqrt(i), i <= max_sims + 1, rounded on the host
+    unsigned long long* counters = nullptr;   // [0] leaf evals, [1] transitions
+};
+
+// meta word of a packed state: bits 0..2 flags (go_board.h), bits 8..9 = area sign + 1
+__host__ __device__ inline uint64_t pack_meta(uint32_t flags, int sign) { return (uint64_t)flags | ((uint64_t)(sign + 1) << 8); }
+__host__ __device__ inline int meta_sign(uint64_t meta) { return (int)((meta >> 8) & 3) - 1; }
+
+int launch_mcts_reset(int S, const Tree& t, const uint8_t* roots, hipStream_t st);
+int launch_mcts_select(int S, const Tree& t, uint8_t* leaf_states_out, hipStream_t st);
+int launch_mcts_backup(int S, const Tree& t, const float* pi_logits, const float* prior, const float* val,
+                       int logits_are_raw, hipStream_t st);
+int launch_mcts_readout(int S, const Tree& t, int32_t* visits, double* prior, int32_t* root_visits, hipStream_t st);
+int launch_mcts_policy(int S, const Tree& t, double temp, double* pi, hipStream_t st);
+int launch_uniform_policy(int S, const Tree& t, int allow_pass, double* pi, hipStream_t st);
+int launch_sample(int S, const Tree& t, const double* pi, uint64_t seed, uint64_t step, int game_offset,
+                  int32_t* actions, hipStream_t st);
+int launch_mcts_advance(int S, const Tree& t, const int32_t* actions, int max_moves, hipStream_t st);
+int launch_mcts_roots(int S, const Tree& t, uint8_t* states, hipStream_t st);
+
+}  // namespace goai

@@ -1,0 +1,127 @@
+// mcts_host.hip -- allocation of the per-game tree arrays and the lock-step search driver:
+// every step is  select (all games) -> CNN forward over the leaf batch -> expand + backup.
+// (/root/reference/go_ai/search/mct.py:50-62 runs the same three phases one leaf at a time.)
+#include <cmath>
+#include <vector>
+
+#include "ctx.h"
+#include "go_board.h"
+#include "goai_internal.h"
+
+namespace goai {
+
+template <typename T>
+static int dev_alloc_t(goai_ctx* c, T** p, size_t count)
+{
+    GOAI_HIP_CHECK(hipMalloc((void**)p, count * sizeof(T)));
+    c->allocs.push_back(*p);
+    return GOAI_OK;
+}
+
+static int state_words(int S)
+{
+    const int P = S * S;
+    return 3 * ((P + 63) / 64) + 1;
+}
+
+int mcts_init(goai_ctx* c, int n_games, int max_sims, int mode)
+{
+    GOAI_REQUIRE(c->tree.n_games == 0, "goai_mcts_init was already called on this context");
+    GOAI_REQUIRE(n_games > 0, "n_games must be positive");
+    // numpy's pairwise mean is maintained incrementally for up to 128 values per node
+    GOAI_REQUIRE(max_sims >= 0 && max_sims <= 128, "max_sims must be in [0, 128]");
+    GOAI_REQUIRE(mode == 0, "only the actor-critic search mode (0) is implemented");
+    Tree& t = c->tree;
+    t.max_sims = max_sims;
+    t.ncap = max_sims + 2;
+    t.mode = mode;
+    const size_t G = n_games, N = G * t.ncap, A = c->A, P = c->P;
+    int rc;
+#define AL(field, count) if ((rc = dev_alloc_t(c, &t.field, (count)))) return rc
+    AL(st, N * state_words(c->S));
+    AL(parent, N); AL(pact, N); AL(visits, N);
+    AL(accR, N * 8); AL(accT, N * 8);
+    AL(prior, N * A); AL(child, N * A); AL(cN, N * A); AL(cQ, N * A);
+    AL(nnodes, G); AL(leaf, G); AL(depth, G); AL(path, N);
+    AL(turn, G); AL(moves, G); AL(result, G);
+    AL(leaf_planes, G * 6 * P); AL(pi_logits, G * A); AL(val_logits, G);
+    AL(sqrt_tab, (size_t)max_sims + 2);
+    AL(counters, 4);
+#undef AL
+    std::vector<double> tab(max_sims + 2);
+    for (int i = 0; i < max_sims + 2; i++) tab[i] = std::sqrt((double)i);   // IEEE correctly rounded on the host
+    GOAI_HIP_CHECK(hipMemcpy(t.sqrt_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    GOAI_HIP_CHECK(hipMemset(t.counters, 0, 4 * sizeof(unsigned long long)));
+    GOAI_HIP_CHECK(hipMemset(t.visits, 0, N * sizeof(int32_t)));
+    t.n_games = n_games;
+    t.steps_since_reset = -1;   // no roots yet
+    return GOAI_OK;
+}
+
+#define REQUIRE_TREE(c) GOAI_REQUIRE((c)->tree.n_games > 0, "call goai_mcts_init first")
+#define REQUIRE_ROOTS(c)                                                                    \
+    do {                                                                                    \
+        REQUIRE_TREE(c);                                                                    \
+        if ((c)->tree.steps_since_reset < 0) { set_error("call goai_mcts_reset first"); return GOAI_ERR_STATE; } \
+    } while (0)
+
+int mcts_reset(goai_ctx* c, const uint8_t* roots)
+{
+    REQUIRE_TREE(c);
+    GOAI_REQUIRE(roots != nullptr, "root_states is NULL");
+    c->tree.steps_since_reset = 0;
+    c->tree.pending_select = false;
+    return launch_mcts_reset(c->S, c->tree, roots, c->stream);
+}
+
+int mcts_select(goai_ctx* c, uint8_t* leaf_states_out)
+{
+    REQUIRE_ROOTS(c);
+    Tree& t = c->tree;
+    if (t.pending_select) { set_error("goai_mcts_select called twice without goai_mcts_backup"); return GOAI_ERR_STATE; }
+    if (t.steps_since_reset > t.max_sims) {
+        set_error("more than max_sims + 1 search steps since the last reset/advance");
+        return GOAI_ERR_STATE;
+    }
+    t.pending_select = true;
+    return launch_mcts_select(c->S, t, leaf_states_out, c->stream);
+}
+
+int mcts_backup(goai_ctx* c, const float* pi_logits, const float* prior, const float* val, int raw)
+{
+    REQUIRE_ROOTS(c);
+    Tree& t = c->tree;
+    if (!t.pending_select) { set_error("goai_mcts_backup without a preceding goai_mcts_select"); return GOAI_ERR_STATE; }
+    GOAI_REQUIRE(val != nullptr, "val_logits is NULL");
+    GOAI_REQUIRE((pi_logits != nullptr) != (prior != nullptr), "pass exactly one of pi_logits / prior");
+    t.pending_select = false;
+    t.steps_since_reset++;
+    return launch_mcts_backup(c->S, t, pi_logits, prior, val, raw, c->stream);
+}
+
+// mct_search(go_env, n_sims): 1 + n_sims steps with the context's own network.
+int mcts_run(goai_ctx* c, int n_sims)
+{
+    REQUIRE_ROOTS(c);
+    Tree& t = c->tree;
+    GOAI_REQUIRE(n_sims >= 0 && n_sims <= t.max_sims, "n_sims exceeds max_sims");
+    GOAI_REQUIRE(c->net.loaded && c->net.kind == 0, "an actor-critic network with loaded weights is required");
+    int rc;
+    for (int s = 0; s < n_sims + 1; s++) {
+        if ((rc = mcts_select(c, nullptr))) return rc;
+        if ((rc = nn_forward_raw(c, t.leaf_planes, t.pi_logits, t.val_logits, t.n_games))) return rc;
+        if ((rc = mcts_backup(c, t.pi_logits, nullptr, t.val_logits, 1))) return rc;
+    }
+    return GOAI_OK;
+}
+
+int mcts_advance(goai_ctx* c, const int32_t* actions)
+{
+    REQUIRE_ROOTS(c);
+    GOAI_REQUIRE(actions != nullptr, "actions is NULL");
+    c->tree.steps_since_reset = 0;
+    c->tree.pending_select = false;
+    return launch_mcts_advance(c->S, c->tree, actions, 2 * c->P, c->stream);
+}
+
+}  // namespace goai

@@ -39,20 +39,21 @@ _SIGNATURES = {
     "goai_mcts_init": [c_void_p, c_int, c_int, c_int],
     "goai_mcts_reset": [c_void_p, c_void_p],
     "goai_mcts_select": [c_void_p, c_void_p],
-    "goai_mcts_backup": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "goai_mcts_backup": [c_void_p, c_void_p, c_void_p, c_void_p, c_int],
     "goai_mcts_run": [c_void_p, c_int],
     "goai_mcts_readout": [c_void_p, c_void_p, c_void_p, c_void_p],
     "goai_mcts_policy": [c_void_p, c_double, c_void_p],
-    "goai_sample_actions": [c_void_p, c_void_p, c_uint64, c_uint64, c_void_p],
+    "goai_uniform_policy": [c_void_p, c_int, c_void_p],
+    "goai_sample_actions": [c_void_p, c_void_p, c_uint64, c_uint64, c_int, c_void_p],
     "goai_mcts_advance": [c_void_p, c_void_p],
+    "goai_mcts_roots": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "goai_mcts_counters": [c_void_p, ctypes.POINTER(c_int64)],
 }
 
 for _name, _args in _SIGNATURES.items():
-    if hasattr(lib, _name):
-        _fn = getattr(lib, _name)
-        _fn.restype = c_int
-        _fn.argtypes = _args
+    _fn = getattr(lib, _name)          # AttributeError here = library older than this binding
+    _fn.restype = c_int
+    _fn.argtypes = _args
 
 
 class GoaiError(RuntimeError):

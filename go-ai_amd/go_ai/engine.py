@@ -118,3 +118,74 @@ class Context:
         val = torch.empty((n, 1), dtype=torch.float32, device=self.device)
         _hip.check(_hip.lib.goai_nn_forward(self._h, _hip.ptr(st), _hip.ptr(pi), _hip.ptr(val), n, int(mode)))
         return pi, val
+
+    # ---- batched search ------------------------------------------------------------
+    def mcts_init(self, n_games, max_sims, mode=0):
+        self.n_games, self.max_sims = int(n_games), int(max_sims)
+        _hip.check(_hip.lib.goai_mcts_init(self._h, self.n_games, self.max_sims, int(mode)))
+
+    def mcts_reset(self, root_states):
+        st = _dev_u8_states(root_states, self.device)
+        assert st.shape == (self.n_games, NUM_CHNLS, self.size, self.size), st.shape
+        _hip.check(_hip.lib.goai_mcts_reset(self._h, _hip.ptr(st)))
+
+    def mcts_select(self, want_leaves=True):
+        leaves = None
+        if want_leaves:
+            leaves = torch.empty((self.n_games, NUM_CHNLS, self.size, self.size), dtype=torch.uint8,
+                                 device=self.device)
+        _hip.check(_hip.lib.goai_mcts_select(self._h, _hip.ptr(leaves)))
+        return leaves
+
+    def mcts_backup(self, val_logits, pi_logits=None, prior=None, logits_are_raw=False):
+        def dev32(x):
+            if x is None:
+                return None
+            x = torch.as_tensor(x)
+            return x.to(self.device, dtype=torch.float32).contiguous()
+        val, pi, pr = dev32(val_logits), dev32(pi_logits), dev32(prior)
+        assert val.numel() == self.n_games
+        _hip.check(_hip.lib.goai_mcts_backup(self._h, _hip.ptr(pi), _hip.ptr(pr), _hip.ptr(val),
+                                             int(bool(logits_are_raw))))
+
+    def mcts_run(self, n_sims):
+        _hip.check(_hip.lib.goai_mcts_run(self._h, int(n_sims)))
+
+    def mcts_readout(self):
+        visits = torch.empty((self.n_games, self.A), dtype=torch.int32, device=self.device)
+        prior = torch.empty((self.n_games, self.A), dtype=torch.float64, device=self.device)
+        root_visits = torch.empty(self.n_games, dtype=torch.int32, device=self.device)
+        _hip.check(_hip.lib.goai_mcts_readout(self._h, _hip.ptr(visits), _hip.ptr(prior), _hip.ptr(root_visits)))
+        return visits, prior, root_visits
+
+    def mcts_policy(self, temp=1.0):
+        pi = torch.empty((self.n_games, self.A), dtype=torch.float64, device=self.device)
+        _hip.check(_hip.lib.goai_mcts_policy(self._h, float(temp), _hip.ptr(pi)))
+        return pi
+
+    def uniform_policy(self, allow_pass=True):
+        pi = torch.empty((self.n_games, self.A), dtype=torch.float64, device=self.device)
+        _hip.check(_hip.lib.goai_uniform_policy(self._h, int(bool(allow_pass)), _hip.ptr(pi)))
+        return pi
+
+    def sample_actions(self, pi, seed, step, game_id_offset=0):
+        actions = torch.empty(self.n_games, dtype=torch.int32, device=self.device)
+        _hip.check(_hip.lib.goai_sample_actions(self._h, _hip.ptr(pi), int(seed), int(step), int(game_id_offset),
+                                                _hip.ptr(actions)))
+        return actions
+
+    def mcts_advance(self, actions):
+        acts = torch.as_tensor(actions).to(self.device, dtype=torch.int32).contiguous()
+        _hip.check(_hip.lib.goai_mcts_advance(self._h, _hip.ptr(acts)))
+
+    def mcts_roots(self):
+        states = torch.empty((self.n_games, NUM_CHNLS, self.size, self.size), dtype=torch.uint8, device=self.device)
+        turn, moves, result = [torch.empty(self.n_games, dtype=torch.int32, device=self.device) for _ in range(3)]
+        _hip.check(_hip.lib.goai_mcts_roots(self._h, _hip.ptr(states), _hip.ptr(turn), _hip.ptr(moves),
+                                            _hip.ptr(result)))
+        return states, turn, moves, result
+
+    def mcts_counters(self):
+        out = (ctypes.c_int64 * 4)()
+        _hip.check(_hip.lib.goai_mcts_counters(self._h, out))
+        return dict(leaf_evals=out[0], transitions=out[1], errors=out[2])

@@ -112,6 +112,77 @@ int goai_load_weights(goai_ctx* ctx, const char* const* names, const float* cons
 int goai_nn_forward(goai_ctx* ctx, const uint8_t* states, float* pi_logits, float* val_logits, int n,
                     int mode);
 
+/* ---------------------------------------------------------------------------------------
+ * Batched Monte-Carlo tree search: n_games independent games per context, one tree each,
+ * advanced in lock step (one leaf per game per step).
+ * ------------------------------------------------------------------------------------- */
+#define GOAI_SEARCH_AC 0   /* mct_search(go_env, n, actor_critic=f), /root/reference/go_ai/search/mct.py:50 */
+
+/* Allocate tree storage for n_games games and at most max_sims searches per move
+ * (max_sims <= 128: numpy's pairwise mean of a node's values, tree.py:180, is maintained
+ * incrementally up to 128 entries). */
+int goai_mcts_init(goai_ctx* ctx, int n_games, int max_sims, int mode);
+
+/* tree.Node(go_env.canonical_state()) for every game (mct.py:52-53): root_states is
+ * [n_games][6][S][S]; the side to move is taken from the turn plane. */
+int goai_mcts_reset(goai_ctx* ctx, const uint8_t* root_states);
+
+/* First half of mct_step (mct.py:20-22): find_next_node for every game -- PUCT descent
+ * (tree.py:170-184, np.nanargmax: first maximum wins) creating at most one node per game
+ * through GoGame.next_state (tree.py:110-117).  leaf_states_out ([n_games][6][S][S], may be
+ * NULL) receives node.state of the selected leaves, i.e. what the reference passes to the
+ * network at mct.py:26. */
+int goai_mcts_select(goai_ctx* ctx, uint8_t* leaf_states_out);
+
+/* Second half of mct_step (mct.py:32-42): node.backprop(val) (tree.py:141-146) and, for
+ * non-terminal leaves, node.set_prior_pi(softmax(pi_logits)).  Exactly one of
+ *   pi_logits [n_games][A] float32 -- logits; the prior is their fp32 softmax, or
+ *   prior     [n_games][A] float32 -- the prior itself (e.g. scipy's softmax output recorded
+ *                                     from the reference; used for bit-exact replay tests)
+ * must be non-NULL.  val_logits is [n_games] float32.  logits_are_raw != 0 means pi_logits /
+ * val_logits come straight from the network and RLNet._numpy's post-processing
+ * (models/__init__.py:90-105) is applied here; 0 means they already went through it. */
+int goai_mcts_backup(goai_ctx* ctx, const float* pi_logits, const float* prior, const float* val_logits,
+                     int logits_are_raw);
+
+/* mct_search with the context's own network: 1 + n_sims times select -> forward -> backup
+ * (mct.py:55-60; the first iteration "doesn't count"). */
+int goai_mcts_run(goai_ctx* ctx, int n_sims);
+
+/* rootnode.get_visit_counts() (tree.py:161-168) -> visit_counts [n_games][A] int32,
+ * rootnode.prior_pi -> prior [n_games][A] float64, rootnode.visits -> root_visits [n_games];
+ * any output may be NULL. */
+int goai_mcts_readout(goai_ctx* ctx, int32_t* visit_counts, double* prior, int32_t* root_visits);
+
+/* ActorCritic.__call__ for mcts > 0 (/root/reference/go_ai/policies/actorcritic.py:29-42):
+ * pi [n_games][A] float64 = 0.98 * normalised(counts ** (1/temp)) + 0.02 * uniform(valid).
+ * Bit-exact for temp == 1.  Finished games get the uniform-valid distribution. */
+int goai_mcts_policy(goai_ctx* ctx, double temp, double* pi);
+
+/* Random policy over the root's valid moves (baselines.Random,
+ * /root/reference/go_ai/policies/baselines.py:108-120); allow_pass = 0 drops the pass unless
+ * nothing else is legal.  Used to build synthetic start positions. */
+int goai_uniform_policy(goai_ctx* ctx, int allow_pass, double* pi);
+
+/* GoGame.random_weighted_action(pi) per game (/root/reference/go_ai/game.py:91) from a
+ * Philox4x32-10 stream keyed by (seed, game_id_offset + game, step): draws do not depend on
+ * how games are sharded over GPUs.  actions is [n_games] int32. */
+int goai_sample_actions(goai_ctx* ctx, const double* pi, uint64_t seed, uint64_t step, int game_id_offset,
+                        int32_t* actions);
+
+/* go_env.step(action) for every running game followed by a fresh tree (game.py:95,
+ * mct.py:52-53).  A game ends after two passes or more than 2*S*S moves (game.py:74,98). */
+int goai_mcts_advance(goai_ctx* ctx, const int32_t* actions);
+
+/* Current roots: canonical states [n_games][6][S][S], side to move (0 black / 1 white), moves
+ * played, result (2 = running, else black's result in {-1,0,1}, game.py:113); any may be NULL. */
+int goai_mcts_roots(goai_ctx* ctx, uint8_t* states, int32_t* turn, int32_t* moves, int32_t* result);
+
+/* Host-side read of 4 counters (synchronises the stream): [0] leaf evaluations of running
+ * games, [1] Go transitions made by the search, [2] internal consistency errors (must stay
+ * 0), [3] reserved. */
+int goai_mcts_counters(goai_ctx* ctx, int64_t* counters_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,150 @@
+"""GPU parity of the tree kernels (select / expand / backup / policy) through the C ABI.
+
+1. Replay of golden searches recorded from the reference's own tree.py / mct.py
+   (tests/golden/mcts_*.npz): the GPU is fed the reference's NN outputs step by step (val
+   logits and the fp32 prior scipy produced) and must select the same leaf STATES at every
+   step and end with bit-identical visit counts, root prior and policy pi.
+2. Same replay but feeding the recorded pi_logits: the prior comes from the GPU's own
+   deterministic fp32 softmax; visit counts must still match the reference on every fixture.
+3. Full GPU search (own CNN) against the CPU oracle running math='det' with the GPU's NN
+   outputs fed back: leaf states, visits and pi bit-exact at the sizes of BASELINE.json.
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load_mcts, mcts_fixture_names
+from helpers import random_positions
+from oracle import mcts_ref, nn_ref
+from oracle.gogame import GoEnv
+
+pytestmark = pytest.mark.gpu
+
+
+def _replay(name, feed):
+    from go_ai.engine import Context
+    size, sims, temp, cases = load_mcts(name)
+    n = len(cases)
+    c = Context(size)
+    c.mcts_init(n, sims)
+    c.mcts_reset(np.stack([cs["root"] for cs in cases]))
+    for s in range(sims + 1):
+        leaves = c.mcts_select().cpu().numpy()
+        for i, cs in enumerate(cases):
+            assert np.array_equal(leaves[i], cs["leaf_states"][s]), f"{name}: case {i} step {s}: different leaf"
+        val = np.array([cs["val_logits"][s] for cs in cases], dtype=np.float32)
+        if feed == "prior":
+            c.mcts_backup(val, prior=np.stack([cs["priors"][s] for cs in cases]))
+        else:
+            c.mcts_backup(val, pi_logits=np.stack([cs["pi_logits"][s] for cs in cases]), logits_are_raw=False)
+    visits, prior, root_visits = [t.cpu().numpy() for t in c.mcts_readout()]
+    pi = c.mcts_policy(temp).cpu().numpy()
+    assert c.mcts_counters()["errors"] == 0
+    c.close()
+    return cases, visits, prior, root_visits, pi
+
+
+@pytest.mark.parametrize("name", mcts_fixture_names())
+def test_replay_reference_search_fed_priors(name):
+    cases, visits, prior, root_visits, pi = _replay(name, "prior")
+    for i, cs in enumerate(cases):
+        assert np.array_equal(visits[i], cs["visits"])
+        assert root_visits[i] == cs["root_visits"]
+        assert np.array_equal(prior[i], cs["root_prior"])
+        assert np.array_equal(pi[i], cs["pi"]), np.abs(pi[i] - cs["pi"]).max()
+
+
+@pytest.mark.parametrize("name", mcts_fixture_names())
+def test_replay_reference_search_fed_logits(name):
+    cases, visits, prior, root_visits, pi = _replay(name, "logits")
+    for i, cs in enumerate(cases):
+        assert np.array_equal(visits[i], cs["visits"])
+        assert np.allclose(prior[i], cs["root_prior"], rtol=2e-6, atol=1e-30)
+        assert np.array_equal(prior[i], mcts_ref.det_softmax32(cs["pi_logits"][0]).astype(np.float64))
+
+
+@pytest.mark.parametrize("size,n_games,sims", [(5, 24, 8), (9, 16, 81), (13, 4, 40)])
+def test_full_search_matches_oracle(size, n_games, sims):
+    """GPU search with its own CNN vs the sequential oracle fed the same NN outputs."""
+    from go_ai.engine import Context
+    c = Context(size)
+    c.nn_init(Context.NET_AC, 3, n_games)
+    sd = nn_ref.make_state_dict("ac", size, 40 + size)
+    c.load_weights(sd)
+    c.mcts_init(n_games, sims)
+    roots = random_positions(size, n_games, seed=300 + size, max_moves=size * size // 2, canonical=True,
+                             pass_prob=0.1)
+    c.mcts_reset(roots)
+    leaf_log, pi_log, val_log = [], [], []
+    for s in range(sims + 1):
+        leaves = c.mcts_select()
+        pi, val = c.nn_forward(leaves, mode=c.NN_NUMPY_SHIM)
+        raw_pi, raw_val = c.nn_forward(leaves, mode=c.NN_RAW)
+        c.mcts_backup(raw_val, pi_logits=raw_pi, logits_are_raw=True)     # fused shim inside the backup
+        leaf_log.append(leaves.cpu().numpy())
+        pi_log.append(pi.cpu().numpy())
+        val_log.append(val.cpu().numpy())
+    visits = c.mcts_readout()[0].cpu().numpy()
+    pis = c.mcts_policy(1.0).cpu().numpy()
+    assert c.mcts_counters() == dict(leaf_evals=n_games * (sims + 1), transitions=c.mcts_counters()["transitions"],
+                                     errors=0)
+    for g in range(n_games):
+        case = dict(leaf_states=[l[g] for l in leaf_log], pi_logits=[p[g] for p in pi_log],
+                    val_logits=[v[g, 0] for v in val_log])
+
+        class Feed:
+            i = 0
+
+            def __call__(self, states):
+                assert np.array_equal(np.asarray(states[0]).astype(np.uint8), case["leaf_states"][self.i]), \
+                    f"game {g} step {self.i}: GPU and oracle selected different leaves"
+                out = case["pi_logits"][self.i][None].copy(), np.asarray([[case["val_logits"][self.i]]], np.float32)
+                self.i += 1
+                return out
+
+        env = GoEnv(size)
+        env.state = roots[g].astype(np.float64)
+        pi, counts, root = mcts_ref.actor_critic_policy(env, Feed(), sims, 1.0, math="det")
+        assert np.array_equal(counts.astype(np.int32), visits[g])
+        assert np.array_equal(pi, pis[g])
+    c.close()
+
+
+def test_run_equals_stepwise_and_advance():
+    """goai_mcts_run == explicit select/forward/backup loop; advance() plays the move."""
+    from go_ai.engine import Context
+    from oracle.gogame import GoGame
+    size, n_games, sims = 9, 32, 20
+    sd = nn_ref.make_state_dict("ac", size, 5)
+    roots = random_positions(size, n_games, seed=9, max_moves=30, canonical=True)
+    res = []
+    for mode in ("run", "steps"):
+        c = Context(size)
+        c.nn_init(Context.NET_AC, 3, n_games)
+        c.load_weights(sd)
+        c.mcts_init(n_games, sims)
+        c.mcts_reset(roots)
+        if mode == "run":
+            c.mcts_run(sims)
+        else:
+            for s in range(sims + 1):
+                leaves = c.mcts_select()
+                pi, val = c.nn_forward(leaves, mode=c.NN_RAW)
+                c.mcts_backup(val, pi_logits=pi, logits_are_raw=True)
+        res.append(c.mcts_readout()[0].cpu().numpy())
+        if mode == "run":
+            pi = c.mcts_policy(1.0)
+            acts = c.sample_actions(pi, seed=1234, step=0)
+            acts2 = c.sample_actions(pi, seed=1234, step=0)
+            assert torch.equal(acts, acts2)
+            a = acts.cpu().numpy()
+            assert (pi.cpu().numpy()[np.arange(n_games), a] > 0).all()
+            c.mcts_advance(acts)
+            states, turn, moves, result = [t.cpu().numpy() for t in c.mcts_roots()]
+            want, status = GoGame.next_states_u8(roots, a, canonical=True)
+            assert (status == 0).all() and np.array_equal(states, want)
+            assert (turn == 1).all() and (moves == 1).all()
+            assert c.mcts_counters()["errors"] == 0
+        c.close()
+    assert np.array_equal(res[0], res[1])
+    assert (res[0].sum(axis=1) == sims).all()
