@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- MCTS leaf evals/sec (9x9, transition + NN forward), BASELINE.json's metric.
+
+Workload (config.workload): BASELINE.json configs[1] -- 9x9 actor-critic net, mcts=81 per
+move (82 leaf evaluations per move and game), 1024 concurrent self-play games per GPU from
+seeded random mid-game positions (k ~ U{0..40} random legal moves), synthetic random-init
+weights (the reference ships none).  One "step" = one move of every game = 82 lock-step
+passes of  select -> Go transition -> CNN forward over the 1024-leaf batch -> expand/backup,
+plus the temperature policy, action sampling and the move itself.  Everything inside the
+timed region runs on the GPU from HBM-resident state.
+
+    python bench.py [--gpus N --steps K --warmup W]      (N > 1: launched by torch.distributed.run)
+
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how each field is obtained.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "go-ai_amd"))
+sys.path.insert(0, ROOT)
+
+SIZE, SIMS, GAMES_PER_GPU, LAYERS = 9, 81, 1024, 3
+PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, matrix fp32
+
+
+# --------------------------------------------------------------------------------------
+# CPU baseline: the oracle's sequential search (reference execution shape: Python tree, one
+# leaf at a time, batch-1 torch CPU forward, children of every leaf for the "assist" path),
+# on `cores` independent single-threaded worker processes like the reference's
+# multi_proc_play (/root/reference/go_ai/utils.py:211-232).  Runs BEFORE the GPU is touched.
+# --------------------------------------------------------------------------------------
+def _cpu_worker(args):
+    wid, seconds = args
+    import numpy as np
+    import torch
+    torch.set_num_threads(1)
+    from oracle import mcts_ref, nn_ref
+    from oracle.gogame import GoEnv, GoGame
+    sd = nn_ref.make_state_dict("ac", SIZE, 0, LAYERS)
+    rng = np.random.default_rng(1234 + wid)
+    env = GoEnv(SIZE)
+    env.reset()
+    for _ in range(int(rng.integers(0, 41))):
+        valid = env.valid_moves()
+        valid[-1] = 0
+        if valid.sum() == 0:
+            break
+        env.step(int(rng.choice(len(valid), p=valid / valid.sum())))
+    evals = 0
+
+    def ac(states):
+        nonlocal evals
+        evals += len(states)
+        return nn_ref.numpy_shim(sd, "ac", "actor_critic", states)
+
+    t0 = time.perf_counter()
+    moves = 0
+    while time.perf_counter() - t0 < seconds:
+        if env.done:
+            env.reset()
+        pi, _, _ = mcts_ref.actor_critic_policy(env, ac, SIMS, 1.0, math="numpy")
+        env.step(GoGame.random_weighted_action(pi))
+        moves += 1
+    return evals, time.perf_counter() - t0, moves
+
+
+def cpu_baseline(seconds):
+    import multiprocessing as mp
+    from oracle import gogame
+    gogame.build()
+    cores = max(1, min(16, os.cpu_count() or 1))
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(w, seconds) for w in range(cores)])
+    value = sum(e / t for e, t, _ in res)
+    return {"value": round(value, 2), "unit": "leaf evals/s", "cores": cores, "kind": "port",
+            "per_core": round(value / cores, 2),
+            "sample": f"{cores} single-threaded worker processes x {seconds:.0f} s of whole moves "
+                      f"(9x9 AC, mcts={SIMS}, oracle search + batch-1 torch CPU forward), "
+                      f"{sum(m for _, _, m in res)} moves, {sum(e for e, _, _ in res)} leaf evals"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--games", type=int, default=GAMES_PER_GPU)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_seconds)          # before any GPU initialisation
+
+    import torch
+    import torch.distributed as dist
+    from go_ai.game import BatchedSelfPlay
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n_games = args.games
+    sp = BatchedSelfPlay(SIZE, n_games, SIMS, temp=1.0, device=local_rank, n_blocks=LAYERS, seed=1234,
+                         game_id_offset=rank * n_games)
+    sp.randomize_starts(40)
+    sp.play(args.warmup)
+    evals0 = sp.ctx.mcts_counters()["leaf_evals"]
+
+    barrier()
+    t0 = time.perf_counter()
+    sp.play(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    st = sp.stats()
+    my_evals = st["leaf_evals"] - evals0
+    assert st["errors"] == 0, st
+
+    # dominant kernel (conv3x3 implicit GEMM): per-launch duration by HIP events on the
+    # kernel's own stream over one more move of the same workload
+    sp.ctx.profile_enable(True)
+    sp.move()
+    conv_ms, conv_n = sp.ctx.profile_read()
+    sp.ctx.profile_enable(False)
+    conv_flop = 2.0 * (n_games * SIZE * SIZE) * 128 * (9 * 128)
+    achieved = conv_flop / (conv_ms / conv_n * 1e-3) / 1e12
+
+    # the one collective of the run: gather per-rank results (utils.py:201-204's allreduces)
+    mine = torch.tensor([my_evals, elapsed, st["games"], st["finished"], st["black_wins"], st["total_steps"]],
+                        dtype=torch.float64, device="cuda")
+    if world > 1:
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu()
+    else:
+        allr = mine[None].cpu()
+    total_evals = float(allr[:, 0].sum())
+    t_max = float(allr[:, 1].max())
+
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "conv3x3_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "MCTS leaf evals/sec (9x9, transition + NN forward)",
+            "value": round(total_evals / t_max, 1),
+            "unit": "leaf evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(t_max / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: 9x9 actor-critic (3 blocks x 128 ch), mcts=81/move, "
+                                   f"{n_games} concurrent games per GPU, step = one move of every game "
+                                   "(82 leaf evals per game)",
+                       "board": SIZE, "mcts": SIMS, "games_per_gpu": n_games, "parallelism": f"games sharded x{world}",
+                       "weights": "random init, seed 0", "leaf_evals_timed": int(total_evals)},
+            "roofline": {"bound": "mfma", "kernel": "k_conv3x3<9>", "achieved": round(achieved, 2),
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "avg_launch_us": round(conv_ms / conv_n * 1e3, 2), "launches_timed": conv_n,
+                         "flop_per_launch": conv_flop},
+            "games": {"total": int(allr[:, 2].sum()), "finished": int(allr[:, 3].sum()),
+                      "black_wins": int(allr[:, 4].sum()), "moves_played": int(allr[:, 5].sum())},
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -213,4 +213,29 @@ int goai_mcts_counters(goai_ctx* ctx, int64_t* counters_host)
     return GOAI_OK;
 }
 
+int goai_profile_enable(goai_ctx* ctx, int enable)
+{
+    CTX_ENTER(ctx);
+    ctx->prof_enabled = enable != 0;
+    return GOAI_OK;
+}
+
+int goai_profile_read(goai_ctx* ctx, double* conv_ms_total, int64_t* conv_launches)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(conv_ms_total && conv_launches, "NULL output");
+    GOAI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    double total = 0.0;
+    for (size_t i = 0; i + 1 < ctx->prof_events.size(); i += 2) {
+        float ms = 0.0f;
+        GOAI_HIP_CHECK(hipEventElapsedTime(&ms, ctx->prof_events[i], ctx->prof_events[i + 1]));
+        total += ms;
+    }
+    *conv_ms_total = total;
+    *conv_launches = (int64_t)(ctx->prof_events.size() / 2);
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    ctx->prof_events.clear();
+    return GOAI_OK;
+}
+
 }  // extern "C"

@@ -14,11 +14,16 @@ struct goai_ctx {
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;   // everything hipMalloc'ed on behalf of this context
     goai::Net net;
+    // optional per-launch timing of the dominant kernel (conv3x3) with HIP events on ctx->stream
+    bool prof_enabled = false;
+    std::vector<hipEvent_t> prof_events;   // start/stop pairs
     goai::Tree tree;
 
     void release()
     {
         for (void* p : allocs) (void)hipFree(p);
+        for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
+        prof_events.clear();
         allocs.clear();
     }
 };

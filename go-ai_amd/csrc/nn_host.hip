@@ -169,6 +169,21 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
     return GOAI_OK;
 }
 
+static int timed_conv(goai_ctx* c, const float* in, const float* w, const float* b, const float* resid, float* out,
+                      int M)
+{
+    if (!c->prof_enabled) return launch_conv3x3(c->S, in, w, b, resid, out, M, c->stream);
+    hipEvent_t e0, e1;
+    GOAI_HIP_CHECK(hipEventCreate(&e0));
+    GOAI_HIP_CHECK(hipEventCreate(&e1));
+    c->prof_events.push_back(e0);
+    c->prof_events.push_back(e1);
+    GOAI_HIP_CHECK(hipEventRecord(e0, c->stream));
+    int rc = launch_conv3x3(c->S, in, w, b, resid, out, M, c->stream);
+    GOAI_HIP_CHECK(hipEventRecord(e1, c->stream));
+    return rc;
+}
+
 // Raw network outputs for n states (pi may be NULL; always NULL-able for the value net).
 int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, int n)
 {
@@ -185,8 +200,8 @@ int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, in
         for (int l = 0; l < net.layers; l++) {
             const float* w1 = net.wt + (size_t)(2 * l) * 9 * 128 * 128;
             const float* w2 = net.wt + (size_t)(2 * l + 1) * 9 * 128 * 128;
-            if ((rc = launch_conv3x3(c->S, x, w1, net.bt + (size_t)(2 * l) * 128, nullptr, y, M, c->stream))) return rc;
-            if ((rc = launch_conv3x3(c->S, y, w2, net.bt + (size_t)(2 * l + 1) * 128, x, z, M, c->stream))) return rc;
+            if ((rc = timed_conv(c, x, w1, net.bt + (size_t)(2 * l) * 128, nullptr, y, M))) return rc;
+            if ((rc = timed_conv(c, y, w2, net.bt + (size_t)(2 * l + 1) * 128, x, z, M))) return rc;
             float* t = x; x = z; z = t;
         }
         if ((rc = launch_heads(c->S, x, net.hw, net.kind == 0 && pi != nullptr, pi ? pi + (size_t)done * A : nullptr, val + done, nb,

@@ -7,6 +7,8 @@ CPU fallback: if the library is missing the import of this module raises.
 import ctypes
 import os
 
+import torch  # noqa: F401  -- first, so that libgoai_hip binds to the HIP runtime torch already loaded
+
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_DIR, "libgoai_hip.so")
 
@@ -48,6 +50,8 @@ _SIGNATURES = {
     "goai_mcts_advance": [c_void_p, c_void_p],
     "goai_mcts_roots": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "goai_mcts_counters": [c_void_p, ctypes.POINTER(c_int64)],
+    "goai_profile_enable": [c_void_p, c_int],
+    "goai_profile_read": [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64)],
 }
 
 for _name, _args in _SIGNATURES.items():

@@ -189,3 +189,12 @@ class Context:
         out = (ctypes.c_int64 * 4)()
         _hip.check(_hip.lib.goai_mcts_counters(self._h, out))
         return dict(leaf_evals=out[0], transitions=out[1], errors=out[2])
+
+    # ---- measurement -----------------------------------------------------------------
+    def profile_enable(self, on=True):
+        _hip.check(_hip.lib.goai_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        _hip.check(_hip.lib.goai_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value

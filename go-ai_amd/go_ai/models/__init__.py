@@ -56,3 +56,87 @@ def random_state_dict(kind, size, seed=0, layers=LAYERS):
     linear(head + ".4", 256, P)
     linear(head + ".6", 1, 256)
     return sd
+
+
+class RLNet:
+    """Counterpart of the reference's RLNet (/root/reference/go_ai/models/__init__.py:13-113),
+    inference half: weights live on the GPU inside a go_ai.engine.Context."""
+    kind = None
+
+    def __init__(self, size, device=0, n_blocks=LAYERS, max_batch=512):
+        from ..engine import Context
+        self.size = size
+        self.layers = n_blocks
+        self.channels = CHANNELS
+        self.assist = True
+        self.requires_children = False
+        self.device_index = device
+        self.max_batch = max_batch
+        self.ctx = Context(size, device)
+        self.ctx.nn_init(Context.NET_AC if self.kind == "ac" else Context.NET_VAL, n_blocks, max_batch)
+        self._sd = None
+        self._search = {}
+        self.load_state_dict(random_state_dict(self.kind, size, seed=0, layers=n_blocks))
+
+    # -- torch.nn.Module look-alikes used by the reference's callers --------------------
+    def load_state_dict(self, state_dict, strict=False):
+        self._sd = {k: (v.detach().cpu().float().clone() if torch.is_tensor(v) else torch.as_tensor(v).float())
+                    for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
+        self.ctx.load_weights(self._sd)
+        for c in self._search.values():
+            c.load_weights(self._sd)
+
+    def state_dict(self):
+        return dict(self._sd)
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    def search_context(self, n_games, max_sims):
+        """A context with tree storage for (n_games, max_sims), sharing this net's weights."""
+        from ..engine import Context
+        key = (n_games, max_sims)
+        if key not in self._search:
+            c = Context(self.size, self.device_index)
+            c.nn_init(Context.NET_AC if self.kind == "ac" else Context.NET_VAL, self.layers, max(n_games, 1))
+            c.load_weights(self._sd)
+            c.mcts_init(n_games, max_sims)
+            self._search[key] = c
+        return self._search[key]
+
+    # -- the numpy shim -----------------------------------------------------------------
+    def create_numpy(self, mode):
+        def np_func(states):
+            return self._numpy(states, mode)
+        return np_func
+
+    def _numpy(self, states, mode, children=None):
+        """RLNet._numpy (models/__init__.py:54-113): numpy in, numpy float32 logits out."""
+        states = np.asarray(states)
+        assert states.ndim == 4, states.shape
+        if mode == "critic":
+            _, val = self.ctx.nn_forward(states, mode=self.ctx.NN_NUMPY_SHIM, want_pi=False)
+            return val.cpu().numpy()
+        if mode not in ("actor", "actor_critic"):
+            raise Exception(f"Unknown mode: {mode}")
+        if self.kind != "ac":
+            raise Exception("Not Implemented")
+        pi, val = self.ctx.nn_forward(states, mode=self.ctx.NN_NUMPY_SHIM)
+        if mode == "actor":
+            return pi.cpu().numpy()
+        return pi.cpu().numpy(), val.cpu().numpy()
+
+
+def get_modelpath(args, savetype):
+    # /root/reference/go_ai/models/__init__.py:285-294
+    import os
+    if savetype == 'checkpoint':
+        d = args.checkdir
+    elif savetype == 'baseline':
+        d = 'bin/baselines/'
+    else:
+        raise Exception(f"Unknown location type: {savetype}")
+    return os.path.join(d, f'{args.model}{args.size}.pt')

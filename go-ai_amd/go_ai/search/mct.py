@@ -1,0 +1,64 @@
+"""mct_search with the reference's signature (/root/reference/go_ai/search/mct.py:50-62),
+executed by the GPU-resident tree kernels.
+
+`actor_critic` may be
+  * the callable returned by `RLNet.create_numpy('actor_critic')` of a go_ai.models net: the
+    whole search (select, CNN forward, expand, backup) then stays on the GPU
+    (goai_mcts_run), or
+  * any other callable f(states[B,6,s,s]) -> (pi_logits[B,A], val_logits[B,1]) with
+    RLNet._numpy semantics (e.g. the reference's torch model): the tree runs on the GPU and f
+    is called once per step on the selected leaf (goai_mcts_select / goai_mcts_backup).
+"""
+import numpy as np
+
+from ..engine import Context
+from .tree import RootView
+
+_plain_ctx = {}
+
+
+def _tree_context(size, num_searches):
+    key = (size, num_searches)
+    if key not in _plain_ctx:
+        c = Context(size)
+        c.mcts_init(1, num_searches)
+        _plain_ctx[key] = c
+    return _plain_ctx[key]
+
+
+def _owning_net(fn):
+    """The go_ai.models net behind a create_numpy closure, if any."""
+    cells = getattr(fn, "__closure__", None) or ()
+    from ..models import RLNet
+    for cell in cells:
+        try:
+            v = cell.cell_contents
+        except ValueError:
+            continue
+        if isinstance(v, RLNet):
+            return v
+    return None
+
+
+def mct_search(go_env, num_searches, actor_critic=None, critic=None):
+    if actor_critic is None:
+        raise NotImplementedError("critic-driven (Q-value) tree search runs through policies.Value")
+    root_state = np.asarray(go_env.canonical_state())
+    size = root_state.shape[-1]
+    net = _owning_net(actor_critic)
+    if net is not None and net.kind == "ac":
+        ctx = net.search_context(1, num_searches)
+        ctx.mcts_reset(root_state[None])
+        ctx.mcts_run(num_searches)
+    else:
+        ctx = _tree_context(size, num_searches)
+        ctx.mcts_reset(root_state[None])
+        for _ in range(num_searches + 1):
+            leaf = ctx.mcts_select().cpu().numpy().astype(np.float64)
+            pi_logits, val_logits = actor_critic(leaf)
+            ctx.mcts_backup(np.asarray(val_logits, dtype=np.float32).reshape(1),
+                            pi_logits=np.asarray(pi_logits, dtype=np.float32).reshape(1, -1), logits_are_raw=False)
+    visits, prior, root_visits = ctx.mcts_readout()
+    root = RootView(root_state, visits[0].cpu().numpy(), prior[0].cpu().numpy(), root_visits[0].item())
+    root._ctx = ctx
+    return root

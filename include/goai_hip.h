@@ -183,6 +183,16 @@ int goai_mcts_roots(goai_ctx* ctx, uint8_t* states, int32_t* turn, int32_t* move
  * 0), [3] reserved. */
 int goai_mcts_counters(goai_ctx* ctx, int64_t* counters_host);
 
+/* ---------------------------------------------------------------------------------------
+ * Measurement aid (no counterpart in the reference, which only logs seconds per game,
+ * /root/reference/go_ai/utils.py:196-207): when enabled, every launch of the dominant kernel
+ * (the 3x3 convolution) is bracketed by HIP events on the context's stream.
+ * goai_profile_read synchronises, returns the summed duration in ms and the launch count, and
+ * clears the record.
+ * ------------------------------------------------------------------------------------- */
+int goai_profile_enable(goai_ctx* ctx, int enable);
+int goai_profile_read(goai_ctx* ctx, double* conv_ms_total, int64_t* conv_launches);
+
 #ifdef __cplusplus
 }
 #endif
