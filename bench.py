@@ -142,16 +142,12 @@ def main():
     achieved = conv_flop / (conv_ms / conv_n * 1e-3) / 1e12
 
     # the one collective of the run: gather per-rank results (utils.py:201-204's allreduces)
-    mine = torch.tensor([my_evals, elapsed, st["games"], st["finished"], st["black_wins"], st["total_steps"]],
-                        dtype=torch.float64, device="cuda")
-    if world > 1:
-        allr = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        allr = torch.stack(allr).cpu()
-    else:
-        allr = mine[None].cpu()
-    total_evals = float(allr[:, 0].sum())
-    t_max = float(allr[:, 1].max())
+    from go_ai.sharding import gather_stats, reduce_stats
+    per_rank = gather_stats(dict(leaf_evals=my_evals, seconds=elapsed, games=st["games"], finished=st["finished"],
+                                 black_wins=st["black_wins"], white_wins=st["white_wins"],
+                                 total_steps=st["total_steps"]), device="cuda")
+    tot = reduce_stats(per_rank)
+    total_evals, t_max = tot["leaf_evals"], tot["seconds"]
 
     if rank == 0:
         traffic = None
@@ -176,8 +172,9 @@ def main():
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "avg_launch_us": round(conv_ms / conv_n * 1e3, 2), "launches_timed": conv_n,
                          "flop_per_launch": conv_flop},
-            "games": {"total": int(allr[:, 2].sum()), "finished": int(allr[:, 3].sum()),
-                      "black_wins": int(allr[:, 4].sum()), "moves_played": int(allr[:, 5].sum())},
+            "games": {"total": int(tot["games"]), "finished": int(tot["finished"]),
+                      "black_wins": int(tot["black_wins"]), "white_wins": int(tot["white_wins"]),
+                      "moves_played": int(tot["total_steps"])},
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu

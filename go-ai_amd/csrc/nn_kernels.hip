@@ -94,7 +94,7 @@ struct ConvCfg {
     static constexpr int NA = (ROWS_A * 8 + 255) / 256;        // float4 per thread per A chunk
 };
 
-template <int S>
+template <int S, bool RESID>
 __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ in, const float* __restrict__ wt,
                                                     const float* __restrict__ bias, const float* __restrict__ resid,
                                                     float* __restrict__ out, int M)
@@ -227,13 +227,29 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ in
         const float bv = bias[col];
 #pragma unroll
         for (int tm = 0; tm < 2; tm++) {
+            const long row0 = (long)m0 + wr * 64 + tm * 32 + 4 * lh;
+            if (m0 + CONV_BM <= M) {
+                // full tile: batch the 16 residual loads, then the 16 stores (no per-element waits)
+                float rv[16];
+                if (RESID) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                long row = (long)m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < M) {
+                    for (int r = 0; r < 16; r++) rv[r] = resid[(row0 + (r & 3) + 8 * (r >> 2)) * 128 + col];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
                     float v = acc[tm][tn][r] + bv;
-                    if (resid) v += resid[row * 128 + col];
-                    out[row * 128 + col] = fmaxf(v, 0.0f);
+                    if (RESID) v += rv[r];
+                    out[(row0 + (r & 3) + 8 * (r >> 2)) * 128 + col] = fmaxf(v, 0.0f);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const long row = row0 + (r & 3) + 8 * (r >> 2);
+                    if (row < M) {
+                        float v = acc[tm][tn][r] + bv;
+                        if (RESID) v += resid[row * 128 + col];
+                        out[row * 128 + col] = fmaxf(v, 0.0f);
+                    }
                 }
             }
         }
@@ -361,7 +377,11 @@ int launch_conv3x3(int S_rt, const float* in, const float* wt, const float* bias
                    int M, hipStream_t st)
 {
     int grid = (M + CONV_BM - 1) / CONV_BM;
-    GOAI_DISPATCH_SIZE(S_rt, k_conv3x3<S><<<dim3(grid), dim3(256), 0, st>>>(in, wt, bias, resid, out, M));
+    if (resid) {
+        GOAI_DISPATCH_SIZE(S_rt, k_conv3x3<S, true><<<dim3(grid), dim3(256), 0, st>>>(in, wt, bias, resid, out, M));
+    } else {
+        GOAI_DISPATCH_SIZE(S_rt, k_conv3x3<S, false><<<dim3(grid), dim3(256), 0, st>>>(in, wt, bias, resid, out, M));
+    }
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }

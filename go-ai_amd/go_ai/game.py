@@ -143,3 +143,6 @@ class BatchedSelfPlay:
         fin = result != 2
         return dict(games=self.n_games, finished=int(fin.sum()), black_wins=int((result == 1).sum()),
                     white_wins=int((result == -1).sum()), total_steps=int(moves.sum()), **cnt)
+
+
+from .sharding import STAT_FIELDS, gather_stats, reduce_stats, shard_games  # noqa: E402,F401

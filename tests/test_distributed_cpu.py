@@ -1,0 +1,51 @@
+"""World-size-2 gloo test (CPU) of the multi-GPU plumbing: game sharding and the single
+result gather.  The search itself never communicates."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "go-ai_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from go_ai import sharding
+    lo, hi = sharding.shard_games(2049, world, rank)
+    rec = dict(leaf_evals=1000 * (rank + 1), seconds=1.0 + rank, games=hi - lo, finished=rank, black_wins=3,
+               white_wins=1, total_steps=10 * (hi - lo))
+    per_rank = sharding.gather_stats(rec)
+    total = sharding.reduce_stats(per_rank)
+    torch.save(dict(per_rank=per_rank, total=total, shard=(lo, hi)), os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_and_sharding_world2(tmp_path):
+    world, port = 2, 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    assert res[0]["shard"] == (0, 1025) and res[1]["shard"] == (1025, 2049)
+    for r in res:
+        assert [p["leaf_evals"] for p in r["per_rank"]] == [1000.0, 2000.0]
+        assert r["total"]["games"] == 2049 and r["total"]["seconds"] == 2.0
+        assert r["total"]["leaf_evals_per_s"] == 1500.0
+        assert r["total"]["total_steps"] == 20490
+
+
+def test_shards_cover_all_games():
+    sys.path.insert(0, os.path.join(ROOT, "go-ai_amd"))
+    from go_ai import sharding
+    for total in (1, 7, 8, 1024, 8192 * 8 + 3):
+        for world in (1, 2, 4, 8):
+            spans = [sharding.shard_games(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,90 @@
+"""The reference-shaped Python surface (go_ai.env / models / search / policies / game) on the GPU:
+the reference's own KAT, golden policies, and a short drop-in game."""
+import types
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN_DIR, ReplayNet, load_mcts, load_nn
+from oracle import nn_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_kat_greedy_and_env():
+    # /root/reference/tests/test_policy.py:16-21,34-43 on the product's env + Value policy
+    from go_ai.env import GoEnv
+    from go_ai.policies import baselines
+    env = GoEnv(5)
+    env.reset()
+    for a in (0, 1, 2, None):
+        env.step(a)
+    args = types.SimpleNamespace(size=5, model='greedy', temp=1, mcts=0)
+    policy, _ = baselines.create_policy(args)
+    pi = policy(env)
+    assert pi[-1] == 1 and np.allclose(pi[:-1], 0)
+    z = np.load(GOLDEN_DIR + "/policy_kat_greedy5.npz")
+    assert np.array_equal(env.state.astype(np.uint8), z["state"])
+    assert np.array_equal(pi, z["pi"])           # the reference's own policy output, bit for bit
+
+
+def test_mct_search_with_foreign_callable_matches_golden():
+    """mct_search driven by a host callable (here: the reference's recorded NN outputs)."""
+    from go_ai.env import GoEnv
+    from go_ai.search import mct
+    size, sims, temp, cases = load_mcts("mcts_ac5_n40")
+    for c in cases[:3]:
+        env = GoEnv(size)
+        env.state = c["root"].astype(np.float64)
+        root = mct.mct_search(env, sims, actor_critic=ReplayNet(c))
+        assert np.array_equal(root.get_visit_counts(), c["visits"])
+        assert root.visits == c["root_visits"]
+
+
+def test_actorcritic_policy_on_gpu_net():
+    from go_ai.env import GoEnv
+    from go_ai.models.ac_net import ActorCriticNet
+    from go_ai.policies.actorcritic import ActorCritic
+    g = load_nn("nn_ac5")
+    net = ActorCriticNet(5, max_batch=32)
+    sd = nn_ref.make_state_dict("ac", 5, int(g["seed"]))
+    net.load_state_dict(sd)
+    assert set(net.state_dict()) == set(sd)
+    # create_numpy keeps the reference's return conventions
+    pi, val = net.create_numpy('actor_critic')(g["states"].astype(np.float64))
+    assert pi.shape == (20, 26) and val.shape == (20, 1) and pi.dtype == np.float32
+    assert np.allclose(val, g["val_np"], rtol=1e-3, atol=1e-3)
+    assert net.create_numpy('critic')(g["states"]).shape == (20, 1)
+    assert net.create_numpy('actor')(g["states"]).shape == (20, 26)
+    policy = ActorCritic("t", net, types.SimpleNamespace(temp=1, mcts=12))
+    env = GoEnv(5)
+    env.reset()
+    env.step(7)
+    pi, qs, root = policy(env, debug=True)
+    assert pi.shape == (26,) and abs(pi.sum() - 1) < 1e-12 and qs.shape == (2, 26)
+    assert root.get_visit_counts().sum() == 12 and root.visits == 13
+    assert pi[7] == 0                                   # occupied point
+    assert str(policy).startswith("ActorCritic[12S 1.00T]")
+
+
+def test_pit_plays_a_legal_game():
+    from go_ai import game
+    from go_ai.env import GoEnv
+    from go_ai.policies.baselines import Random
+    np.random.seed(0)
+    env = GoEnv(5)
+    black_won, steps, traj = game.pit(env, Random(), Random())
+    assert black_won in (-1, 0, 1) and 2 <= steps <= 2 * 25 + 1 and len(traj) == steps
+    ev = traj.get_events()
+    assert ev[-1][4] is True and ev[0][3].shape == (26, 6, 5, 5)
+
+
+def test_batched_selfplay_runs_games_to_the_end():
+    from go_ai.game import BatchedSelfPlay
+    sp = BatchedSelfPlay(5, 64, 6, seed=3)
+    sp.randomize_starts(10)
+    sp.play(2 * 25 + 2)
+    st = sp.stats()
+    assert st["finished"] == 64 and st["errors"] == 0
+    assert st["black_wins"] + st["white_wins"] <= 64
+    assert 0 < st["leaf_evals"] <= 64 * 7 * 52
