@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--games", type=int, default=GAMES_PER_GPU)
+    ap.add_argument("--groups", type=int, default=1, help="independent game groups on separate HIP streams")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,10 +118,10 @@ def main():
 
     n_games = args.games
     sp = BatchedSelfPlay(SIZE, n_games, SIMS, temp=1.0, device=local_rank, n_blocks=LAYERS, seed=1234,
-                         game_id_offset=rank * n_games)
+                         game_id_offset=rank * n_games, groups=args.groups)
     sp.randomize_starts(40)
     sp.play(args.warmup)
-    evals0 = sp.ctx.mcts_counters()["leaf_evals"]
+    evals0 = sp.counters()["leaf_evals"]
 
     barrier()
     t0 = time.perf_counter()
@@ -134,11 +135,8 @@ def main():
 
     # dominant kernel (conv3x3 implicit GEMM): per-launch duration by HIP events on the
     # kernel's own stream over one more move of the same workload
-    sp.ctx.profile_enable(True)
-    sp.move()
-    conv_ms, conv_n = sp.ctx.profile_read()
-    sp.ctx.profile_enable(False)
-    conv_flop = 2.0 * (n_games * SIZE * SIZE) * 128 * (9 * 128)
+    conv_ms, conv_n = sp.profile_conv()
+    conv_flop = 2.0 * (n_games // len(sp.groups) * SIZE * SIZE) * 128 * (9 * 128)
     achieved = conv_flop / (conv_ms / conv_n * 1e-3) / 1e12
 
     # the one collective of the run: gather per-rank results (utils.py:201-204's allreduces)
@@ -166,6 +164,7 @@ def main():
                                    f"{n_games} concurrent games per GPU, step = one move of every game "
                                    "(82 leaf evals per game)",
                        "board": SIZE, "mcts": SIMS, "games_per_gpu": n_games, "parallelism": f"games sharded x{world}",
+                       "stream_groups_per_gpu": len(sp.groups),
                        "weights": "random init, seed 0", "leaf_evals_timed": int(total_evals)},
             "roofline": {"bound": "mfma", "kernel": "k_conv3x3<9>", "achieved": round(achieved, 2),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

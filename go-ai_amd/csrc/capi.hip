@@ -150,7 +150,14 @@ int goai_mcts_backup(goai_ctx* ctx, const float* pi_logits, const float* prior, 
 int goai_mcts_run(goai_ctx* ctx, int n_sims)
 {
     CTX_ENTER(ctx);
-    return mcts_run(ctx, n_sims);
+    GOAI_REQUIRE(n_sims >= 0, "n_sims < 0");
+    return mcts_steps(ctx, n_sims + 1);
+}
+
+int goai_mcts_steps(goai_ctx* ctx, int n_steps)
+{
+    CTX_ENTER(ctx);
+    return mcts_steps(ctx, n_steps);
 }
 
 int goai_mcts_readout(goai_ctx* ctx, int32_t* visit_counts, double* prior, int32_t* root_visits)

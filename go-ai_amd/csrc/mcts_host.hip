@@ -99,15 +99,16 @@ int mcts_backup(goai_ctx* c, const float* pi_logits, const float* prior, const f
     return launch_mcts_backup(c->S, t, pi_logits, prior, val, raw, c->stream);
 }
 
-// mct_search(go_env, n_sims): 1 + n_sims steps with the context's own network.
-int mcts_run(goai_ctx* c, int n_sims)
+// n_steps x mct_step with the context's own network (mct_search = 1 + n_sims of them).
+int mcts_steps(goai_ctx* c, int n_steps)
 {
     REQUIRE_ROOTS(c);
     Tree& t = c->tree;
-    GOAI_REQUIRE(n_sims >= 0 && n_sims <= t.max_sims, "n_sims exceeds max_sims");
+    GOAI_REQUIRE(n_steps >= 0 && t.steps_since_reset + n_steps <= t.max_sims + 1,
+                 "more than max_sims + 1 search steps since the last reset/advance");
     GOAI_REQUIRE(c->net.loaded && c->net.kind == 0, "an actor-critic network with loaded weights is required");
     int rc;
-    for (int s = 0; s < n_sims + 1; s++) {
+    for (int s = 0; s < n_steps; s++) {
         if ((rc = mcts_select(c, nullptr))) return rc;
         if ((rc = nn_forward_raw(c, t.leaf_planes, t.pi_logits, t.val_logits, t.n_games))) return rc;
         if ((rc = mcts_backup(c, t.pi_logits, nullptr, t.val_logits, 1))) return rc;

@@ -7,16 +7,14 @@
 // reference, models/__init__.py:64).
 //
 // Data layout: activations are channel-last fp32, act[row][128] with row = board*P + cell,
-// so a 3x3 convolution is an implicit GEMM  out[M = B*P][128] = sum over 9 taps of
-// shift_tap(act)[M][128] x W_tap[128][128]  on the fp32 matrix cores
-// (v_mfma_f32_32x32x2_f32, exact fp32 fma chains).
+// so a 3x3 convolution is an implicit GEMM over flat rows (conv_kernels.hip).  This file
+// holds the small kernels around it: the first convolution, the heads, the numpy shim.
 #include "go_board.h"
 #include "goai_internal.h"
 #include "nn.h"
 
 namespace goai {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // --------------------------------------------------------------------------------------
@@ -63,195 +61,6 @@ __global__ __launch_bounds__(256) void k_conv0(const uint8_t* __restrict__ state
                 acc = fmaf(hi[1], w[5 * 9 + t], acc);
             }
             out[((size_t)b * G::P + p) * 128 + cout] = fmaxf(acc, 0.0f);
-        }
-    }
-}
-
-// --------------------------------------------------------------------------------------
-// conv3x3 128 -> 128 (+ folded BN bias, optional residual, ReLU) as an implicit GEMM on
-// v_mfma_f32_32x32x2_f32.
-//
-// Workgroup = 4 waves = a 128-row x 128-channel output tile over FLAT rows (tiles may span
-// boards); each wave owns 64x64 = 2x2 MFMA tiles (64 accumulator registers).
-// K = 9 taps x 128 input channels is walked as 4 channel chunks x 9 taps ("stages"):
-//   - the A image (tile rows + a halo of S+1 rows either side, 32 channels) is staged in LDS
-//     once per chunk and re-read with a per-tap row shift; rows whose tap falls off the
-//     board read a dedicated zero row, so the inner loop has no branches;
-//   - the B image (W_tap^T, [128 out][32 in], 16 KiB) is double-buffered: the next stage's
-//     weights are fetched into registers while the MFMAs of this stage run.
-// LDS rows are padded 32 -> 36 floats: ds_read_b128 of 16 consecutive rows is conflict-free.
-// --------------------------------------------------------------------------------------
-constexpr int CONV_BM = 128;
-constexpr int CONV_CK = 32;
-constexpr int CONV_LD = 36;
-
-template <int S>
-struct ConvCfg {
-    static constexpr int HALO = S + 1;
-    static constexpr int ROWS_A = CONV_BM + 2 * HALO;          // data rows; row ROWS_A is the zero row
-    static constexpr int A_FLOATS = (ROWS_A + 1) * CONV_LD;
-    static constexpr int B_FLOATS = 128 * CONV_LD;
-    static constexpr int NA = (ROWS_A * 8 + 255) / 256;        // float4 per thread per A chunk
-};
-
-template <int S, bool RESID>
-__global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ in, const float* __restrict__ wt,
-                                                    const float* __restrict__ bias, const float* __restrict__ resid,
-                                                    float* __restrict__ out, int M)
-{
-    using G = Geom<S>;
-    using C = ConvCfg<S>;
-    __shared__ __attribute__((aligned(16))) float lds[C::A_FLOATS + 2 * C::B_FLOATS];
-    float* As = lds;
-    float* Bs = lds + C::A_FLOATS;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.x * CONV_BM;
-    const int li = lane & 31, lh = lane >> 5;
-
-    // zero row
-    if (tid < CONV_LD) As[C::ROWS_A * CONV_LD + tid] = 0.0f;
-
-    // per-lane geometry of the two 32-row tiles this wave owns
-    int rloc[2], rr[2], cc[2];
-    bool mvalid[2];
-#pragma unroll
-    for (int tm = 0; tm < 2; tm++) {
-        rloc[tm] = wr * 64 + tm * 32 + li;
-        int m = m0 + rloc[tm];
-        mvalid[tm] = m < M;
-        int p = m % G::P;
-        rr[tm] = p / S;
-        cc[tm] = p % S;
-    }
-    int boff[2];
-#pragma unroll
-    for (int tn = 0; tn < 2; tn++) boff[tn] = (wc * 64 + tn * 32 + li) * CONV_LD + lh * 4;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-
-    f32x4 breg[4];
-    f32x4 areg[C::NA];
-
-    auto load_a = [&](int chunk) {
-#pragma unroll
-        for (int i = 0; i < C::NA; i++) {
-            int idx = tid + i * 256;
-            int row = idx >> 3, piece = idx & 7;
-            long grow = (long)m0 - C::HALO + row;
-            f32x4 v = { 0.0f, 0.0f, 0.0f, 0.0f };
-            if (row < C::ROWS_A && grow >= 0 && grow < M)
-                v = *reinterpret_cast<const f32x4*>(&in[grow * 128 + chunk * CONV_CK + piece * 4]);
-            areg[i] = v;
-        }
-    };
-    auto store_a = [&]() {
-#pragma unroll
-        for (int i = 0; i < C::NA; i++) {
-            int idx = tid + i * 256;
-            int row = idx >> 3, piece = idx & 7;
-            if (row < C::ROWS_A) *reinterpret_cast<f32x4*>(&As[row * CONV_LD + piece * 4]) = areg[i];
-        }
-    };
-    auto load_b = [&](int stage) {
-        const float* src = wt + (size_t)stage * 128 * CONV_CK;
-#pragma unroll
-        for (int i = 0; i < 4; i++) breg[i] = *reinterpret_cast<const f32x4*>(&src[(tid + i * 256) * 4]);
-    };
-    auto store_b = [&](int buf) {
-        float* dst = Bs + buf * C::B_FLOATS;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int idx = tid + i * 256;
-            *reinterpret_cast<f32x4*>(&dst[(idx >> 3) * CONV_LD + (idx & 7) * 4]) = breg[i];
-        }
-    };
-
-    load_a(0);
-    load_b(0);
-    store_a();
-    store_b(0);
-    __syncthreads();
-
-    constexpr int NSTAGE = 4 * 9;
-    for (int s = 0; s < NSTAGE; s++) {
-        const int chunk = s / 9, tap = s - chunk * 9;
-        const int buf = s & 1;
-        if (s + 1 < NSTAGE) load_b(s + 1);
-        const bool next_chunk = (tap == 8) && (chunk + 1 < 4);
-        if (next_chunk) load_a(chunk + 1);
-
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        int aoff[2];
-#pragma unroll
-        for (int tm = 0; tm < 2; tm++) {
-            bool ok = mvalid[tm] && (unsigned)(rr[tm] + dy) < (unsigned)S && (unsigned)(cc[tm] + dx) < (unsigned)S;
-            int srow = ok ? (rloc[tm] + C::HALO + dy * S + dx) : C::ROWS_A;
-            aoff[tm] = srow * CONV_LD + lh * 4;
-        }
-        const float* Bb = Bs + buf * C::B_FLOATS;
-#pragma unroll
-        for (int kk = 0; kk < CONV_CK / 8; kk++) {
-            f32x4 a[2], b[2];
-#pragma unroll
-            for (int tm = 0; tm < 2; tm++) a[tm] = *reinterpret_cast<const f32x4*>(&As[aoff[tm] + kk * 8]);
-#pragma unroll
-            for (int tn = 0; tn < 2; tn++) b[tn] = *reinterpret_cast<const f32x4*>(&Bb[boff[tn] + kk * 8]);
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int tm = 0; tm < 2; tm++)
-#pragma unroll
-                    for (int tn = 0; tn < 2; tn++)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
-        }
-        if (s + 1 < NSTAGE) store_b(buf ^ 1);      // buf^1 was last read in stage s-1
-        if (next_chunk) {
-            __syncthreads();                        // everyone is done with this chunk's A image
-            store_a();
-        }
-        __syncthreads();
-    }
-
-    // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int tn = 0; tn < 2; tn++) {
-        const int col = wc * 64 + tn * 32 + li;
-        const float bv = bias[col];
-#pragma unroll
-        for (int tm = 0; tm < 2; tm++) {
-            const long row0 = (long)m0 + wr * 64 + tm * 32 + 4 * lh;
-            if (m0 + CONV_BM <= M) {
-                // full tile: batch the 16 residual loads, then the 16 stores (no per-element waits)
-                float rv[16];
-                if (RESID) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) rv[r] = resid[(row0 + (r & 3) + 8 * (r >> 2)) * 128 + col];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    float v = acc[tm][tn][r] + bv;
-                    if (RESID) v += rv[r];
-                    out[(row0 + (r & 3) + 8 * (r >> 2)) * 128 + col] = fmaxf(v, 0.0f);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const long row = row0 + (r & 3) + 8 * (r >> 2);
-                    if (row < M) {
-                        float v = acc[tm][tn][r] + bv;
-                        if (RESID) v += resid[row * 128 + col];
-                        out[row * 128 + col] = fmaxf(v, 0.0f);
-                    }
-                }
-            }
         }
     }
 }
@@ -369,19 +178,6 @@ int launch_conv0(int S_rt, const uint8_t* states, const float* w0, const float* 
 {
     int grid = nboards < 4096 ? nboards : 4096;
     GOAI_DISPATCH_SIZE(S_rt, k_conv0<S><<<dim3(grid), dim3(256), 0, st>>>(states, w0, b0, shift, out, nboards));
-    GOAI_HIP_CHECK(hipGetLastError());
-    return GOAI_OK;
-}
-
-int launch_conv3x3(int S_rt, const float* in, const float* wt, const float* bias, const float* resid, float* out,
-                   int M, hipStream_t st)
-{
-    int grid = (M + CONV_BM - 1) / CONV_BM;
-    if (resid) {
-        GOAI_DISPATCH_SIZE(S_rt, k_conv3x3<S, true><<<dim3(grid), dim3(256), 0, st>>>(in, wt, bias, resid, out, M));
-    } else {
-        GOAI_DISPATCH_SIZE(S_rt, k_conv3x3<S, false><<<dim3(grid), dim3(256), 0, st>>>(in, wt, bias, resid, out, M));
-    }
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }

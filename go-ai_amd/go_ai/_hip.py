@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  -- first, so that libgoai_hip binds to the HIP runtime torch already loaded
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_DIR, "libgoai_hip.so")
+LIB_PATH = os.environ.get("GOAI_HIP_LIB", os.path.join(_PKG_DIR, "libgoai_hip.so"))   # override: diagnostic builds
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -43,6 +43,7 @@ _SIGNATURES = {
     "goai_mcts_select": [c_void_p, c_void_p],
     "goai_mcts_backup": [c_void_p, c_void_p, c_void_p, c_void_p, c_int],
     "goai_mcts_run": [c_void_p, c_int],
+    "goai_mcts_steps": [c_void_p, c_int],
     "goai_mcts_readout": [c_void_p, c_void_p, c_void_p, c_void_p],
     "goai_mcts_policy": [c_void_p, c_double, c_void_p],
     "goai_uniform_policy": [c_void_p, c_int, c_void_p],

@@ -151,6 +151,9 @@ class Context:
     def mcts_run(self, n_sims):
         _hip.check(_hip.lib.goai_mcts_run(self._h, int(n_sims)))
 
+    def mcts_steps(self, n_steps):
+        _hip.check(_hip.lib.goai_mcts_steps(self._h, int(n_steps)))
+
     def mcts_readout(self):
         visits = torch.empty((self.n_games, self.A), dtype=torch.int32, device=self.device)
         prior = torch.empty((self.n_games, self.A), dtype=torch.float64, device=self.device)

@@ -82,67 +82,125 @@ def play_games(go_env, first_policy, second_policy, episodes, progress=False):
 
 
 class BatchedSelfPlay:
-    """n_games concurrent self-play games of one actor-critic net with `mcts` searches/move."""
+    """n_games concurrent self-play games of one actor-critic net with `mcts` searches/move.
+
+    The games are split into `groups` independent groups, each with its own context and HIP
+    stream.  Their search steps are enqueued interleaved, so while one group's convolutions
+    occupy the matrix cores the other group's tree kernels, heads and kernel tails run beside
+    them (the groups never exchange data; results do not depend on the grouping)."""
 
     def __init__(self, size, n_games, mcts, temp=1.0, state_dict=None, device=0, n_blocks=3, seed=1234,
-                 game_id_offset=0):
+                 game_id_offset=0, groups=1):
         from .models import random_state_dict
+        from .sharding import shard_games
         self.size, self.n_games, self.mcts, self.temp = size, n_games, mcts, temp
         self.seed, self.game_id_offset = seed, game_id_offset
-        self.ctx = Context(size, device)
-        self.ctx.nn_init(Context.NET_AC, n_blocks, n_games)
-        self.ctx.load_weights(state_dict if state_dict is not None else random_state_dict("ac", size, 0, n_blocks))
-        self.ctx.mcts_init(n_games, mcts)
+        groups = max(1, min(groups, n_games))
+        sd = state_dict if state_dict is not None else random_state_dict("ac", size, 0, n_blocks)
+        self.groups = []
+        dev = torch.device("cuda", device)
+        for gi in range(groups):
+            lo, hi = shard_games(n_games, groups, gi)
+            stream = torch.cuda.current_stream(dev) if groups == 1 else torch.cuda.Stream(dev)
+            c = Context(size, device)
+            c.set_stream(stream)
+            c.nn_init(Context.NET_AC, n_blocks, hi - lo)
+            c.load_weights(sd)
+            c.mcts_init(hi - lo, mcts)
+            self.groups.append((c, stream, game_id_offset + lo))
+        self.ctx = self.groups[0][0]
         self.move_index = 0
         self.reset()
 
+    def _each(self):
+        for c, stream, off in self.groups:
+            with torch.cuda.stream(stream):
+                yield c, off
+
+    def sync(self):
+        for _, stream, _ in self.groups:
+            stream.synchronize()
+
     def reset(self, root_states=None):
-        if root_states is None:
-            root_states = torch.zeros((self.n_games, 6, self.size, self.size), dtype=torch.uint8,
-                                      device=self.ctx.device)
-        self.ctx.mcts_reset(root_states)
+        lo = 0
+        for c, _ in self._each():
+            if root_states is None:
+                roots = torch.zeros((c.n_games, 6, self.size, self.size), dtype=torch.uint8, device=c.device)
+            else:
+                roots = root_states[lo:lo + c.n_games]
+            c.mcts_reset(roots)
+            lo += c.n_games
         self.move_index = 0
 
     def randomize_starts(self, max_random_moves=40):
         """Advance game g by k_g ~ U{0..max_random_moves} uniformly random legal non-pass moves
         (Philox stream per game id), so that trees differ."""
-        c = self.ctx
         gen = torch.Generator().manual_seed(self.seed)
-        k = torch.randint(0, max_random_moves + 1, (1 << 20,), generator=gen)
-        idx = (torch.arange(self.n_games) + self.game_id_offset) % (1 << 20)
-        k = k[idx].to(c.device)
-        states = c.mcts_roots()[0]
-        for i in range(max_random_moves):
+        ktab = torch.randint(0, max_random_moves + 1, (1 << 20,), generator=gen)
+        for c, off in self._each():
+            k = ktab[(torch.arange(c.n_games) + off) % (1 << 20)].to(c.device)
+            states = c.mcts_roots()[0]
+            for i in range(max_random_moves):
+                c.mcts_reset(states)
+                pi = c.uniform_policy(allow_pass=False)
+                acts = c.sample_actions(pi, self.seed ^ 0x5eed, i, off)
+                nxt, status = c.transition(states, acts, canonical=True)
+                take = (k > i) & (status == 0)
+                states = torch.where(take[:, None, None, None], nxt, states)
             c.mcts_reset(states)
-            pi = c.uniform_policy(allow_pass=False)
-            acts = c.sample_actions(pi, self.seed ^ 0x5eed, i, self.game_id_offset)
-            nxt, status = c.transition(states, acts, canonical=True)
-            take = (k > i) & (status == 0)
-            states = torch.where(take[:, None, None, None], nxt, states)
-        c.mcts_reset(states)
+        self.sync()
         self.move_index = 0
 
     def move(self):
         """One move for every running game: search, policy, temperature-sampled action, step."""
-        c = self.ctx
-        c.mcts_run(self.mcts)
-        pi = c.mcts_policy(self.temp)
-        acts = c.sample_actions(pi, self.seed, self.move_index, self.game_id_offset)
-        c.mcts_advance(acts)
+        if len(self.groups) == 1:
+            self.ctx.mcts_run(self.mcts)
+        else:
+            for _ in range(self.mcts + 1):
+                for c, _ in self._each():
+                    c.mcts_steps(1)
+        out = []
+        for c, off in self._each():
+            pi = c.mcts_policy(self.temp)
+            acts = c.sample_actions(pi, self.seed, self.move_index, off)
+            c.mcts_advance(acts)
+            out.append((pi, acts))
         self.move_index += 1
-        return pi, acts
+        return out
 
     def play(self, n_moves):
         for _ in range(n_moves):
             self.move()
 
+    def counters(self):
+        tot = dict(leaf_evals=0, transitions=0, errors=0)
+        for c, _ in self._each():
+            for k, v in c.mcts_counters().items():
+                tot[k] += v
+        return tot
+
     def stats(self):
-        c = self.ctx
-        _, turn, moves, result = [t.cpu().numpy() for t in c.mcts_roots()]
-        cnt = c.mcts_counters()
-        fin = result != 2
-        return dict(games=self.n_games, finished=int(fin.sum()), black_wins=int((result == 1).sum()),
-                    white_wins=int((result == -1).sum()), total_steps=int(moves.sum()), **cnt)
+        res, mv = [], []
+        for c, _ in self._each():
+            _, turn, moves, result = [t.cpu().numpy() for t in c.mcts_roots()]
+            res.append(result)
+            mv.append(moves)
+        import numpy as _np
+        result, moves = _np.concatenate(res), _np.concatenate(mv)
+        return dict(games=self.n_games, finished=int((result != 2).sum()), black_wins=int((result == 1).sum()),
+                    white_wins=int((result == -1).sum()), total_steps=int(moves.sum()), **self.counters())
+
+    def profile_conv(self):
+        """Time every conv3x3 launch of one more move with HIP events on the launch streams."""
+        for c, _ in self._each():
+            c.profile_enable(True)
+        self.move()
+        ms, n = 0.0, 0
+        for c, _ in self._each():
+            m, k = c.profile_read()
+            c.profile_enable(False)
+            ms, n = ms + m, n + k
+        return ms, n
 
 
 from .sharding import STAT_FIELDS, gather_stats, reduce_stats, shard_games  # noqa: E402,F401

@@ -149,6 +149,11 @@ int goai_mcts_backup(goai_ctx* ctx, const float* pi_logits, const float* prior, 
  * (mct.py:55-60; the first iteration "doesn't count"). */
 int goai_mcts_run(goai_ctx* ctx, int n_sims);
 
+/* n_steps x mct_step (select -> forward -> backup) with the context's own network; lets a
+ * caller interleave the steps of several contexts (game groups) on different streams so that
+ * one group's tree kernels and kernel tails overlap the other group's convolutions. */
+int goai_mcts_steps(goai_ctx* ctx, int n_steps);
+
 /* rootnode.get_visit_counts() (tree.py:161-168) -> visit_counts [n_games][A] int32,
  * rootnode.prior_pi -> prior [n_games][A] float64, rootnode.visits -> root_visits [n_games];
  * any output may be NULL. */

@@ -29,7 +29,7 @@ def lib():
 def test_header_declares_the_expected_surface():
     names = declared_functions()
     for must in ("goai_transition", "goai_children", "goai_score", "goai_nn_forward", "goai_load_weights",
-                 "goai_mcts_select", "goai_mcts_backup", "goai_mcts_run", "goai_mcts_readout", "goai_mcts_policy",
+                 "goai_mcts_select", "goai_mcts_backup", "goai_mcts_run", "goai_mcts_steps", "goai_mcts_readout", "goai_mcts_policy",
                  "goai_sample_actions", "goai_mcts_advance"):
         assert must in names
 
