@@ -19,7 +19,7 @@ using namespace goai;
 extern "C" {
 
 const char* goai_last_error(void) { return g_last_error.c_str(); }
-int goai_version(void) { return 1; }
+int goai_version(void) { return 2; }
 
 int goai_ctx_create(goai_ctx** out, int device, int board_size)
 {
@@ -145,6 +145,36 @@ int goai_mcts_backup(goai_ctx* ctx, const float* pi_logits, const float* prior, 
 {
     CTX_ENTER(ctx);
     return mcts_backup(ctx, pi_logits, prior, val_logits, logits_are_raw);
+}
+
+int goai_mcts_expand(goai_ctx* ctx, uint8_t* children_out, uint8_t* valid_out)
+{
+    CTX_ENTER(ctx);
+    return mcts_expand(ctx, children_out, valid_out);
+}
+
+int goai_mcts_backup_q(goai_ctx* ctx, const double* leaf_val, const double* child_vals, int vals_are_raw)
+{
+    CTX_ENTER(ctx);
+    return mcts_backup_q(ctx, leaf_val, child_vals, vals_are_raw);
+}
+
+int goai_mcts_child_values(goai_ctx* ctx, double* inverted_child_vals)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(ctx->tree.steps_since_reset >= 0, "call goai_mcts_init and goai_mcts_reset first");
+    GOAI_REQUIRE(ctx->tree.mode == GOAI_SEARCH_Q, "needs a context initialised with GOAI_SEARCH_Q");
+    GOAI_REQUIRE(inverted_child_vals != nullptr, "NULL output");
+    return launch_q_child_values(ctx->S, ctx->tree, inverted_child_vals, ctx->stream);
+}
+
+int goai_mcts_policy_value(goai_ctx* ctx, double temp, int from_values, double* pi)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(ctx->tree.steps_since_reset >= 0, "call goai_mcts_init and goai_mcts_reset first");
+    GOAI_REQUIRE(ctx->tree.mode == GOAI_SEARCH_Q, "needs a context initialised with GOAI_SEARCH_Q");
+    GOAI_REQUIRE(pi != nullptr && temp > 0.0, "pi is NULL or temp <= 0");
+    return launch_q_policy(ctx->S, ctx->tree, temp, from_values, pi, ctx->stream);
 }
 
 int goai_mcts_run(goai_ctx* ctx, int n_sims)

@@ -13,6 +13,7 @@ struct goai_ctx {
     int S = 0, P = 0, A = 0;
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;   // everything hipMalloc'ed on behalf of this context
+    std::vector<void*> host_allocs;   // pinned host memory
     goai::Net net;
     // optional per-launch timing of the dominant kernel (conv3x3) with HIP events on ctx->stream
     bool prof_enabled = false;
@@ -22,6 +23,8 @@ struct goai_ctx {
     void release()
     {
         for (void* p : allocs) (void)hipFree(p);
+        for (void* p : host_allocs) (void)hipHostFree(p);
+        host_allocs.clear();
         for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
         prof_events.clear();
         allocs.clear();

@@ -55,6 +55,8 @@ int mcts_init(goai_ctx* c, int n_games, int max_sims, int mode);
 int mcts_reset(goai_ctx* c, const uint8_t* roots);
 int mcts_select(goai_ctx* c, uint8_t* leaf_states_out);
 int mcts_backup(goai_ctx* c, const float* pi_logits, const float* prior, const float* val, int raw);
+int mcts_expand(goai_ctx* c, uint8_t* children_out, uint8_t* valid_out);
+int mcts_backup_q(goai_ctx* c, const double* leaf_val, const double* child_vals, int raw);
 int mcts_steps(goai_ctx* c, int n_steps);
 int mcts_advance(goai_ctx* c, const int32_t* actions);
 

@@ -11,17 +11,22 @@
 namespace goai {
 
 struct Tree {
-    int n_games = 0, max_sims = 0, ncap = 0, mode = 0;
+    int n_games = 0, max_sims = 0, mode = 0;
+    int ncap = 0;                // nodes per game: AC max_sims + 2 (one new node per step); Q 2 + (max_sims + 1) * A
+    int rcap = 0;                // expanded nodes (rows) and path entries per game: max_sims + 2 in both modes
     int steps_since_reset = 0;
     bool pending_select = false;
+    int pending_expand = 0;      // Q mode: 1 after select, 2 after expand
     // nodes: [G][ncap]
     uint64_t* st = nullptr;      // [..][SW] packed state: me[K], opp[K], inv[K], meta
     int32_t* parent = nullptr;
     int32_t* pact = nullptr;     // action that led here
     int32_t* visits = nullptr;
+    int32_t* rowof = nullptr;    // row of an expanded node (set by select when the node becomes a non-terminal leaf)
+    double* nval = nullptr;      // Q mode: node.val (tree.py:122-126), the critic's value of the node's state
     double* accR = nullptr;      // [..][8] lane accumulators of numpy's pairwise sum over full blocks of 8
     double* accT = nullptr;      // [..][8] pending tail (visits % 8 entries)
-    // rows: [G][ncap][A]
+    // rows: [G][rcap][A]
     double* prior = nullptr;
     int32_t* child = nullptr;
     int32_t* cN = nullptr;       // child visit counts
@@ -30,7 +35,8 @@ struct Tree {
     int32_t* nnodes = nullptr;
     int32_t* leaf = nullptr;
     int32_t* depth = nullptr;
-    int32_t* path = nullptr;     // [G][ncap]
+    int32_t* nrows = nullptr;
+    int32_t* path = nullptr;     // [G][rcap]
     int32_t* turn = nullptr;     // absolute colour to move at the root (0 black, 1 white)
     int32_t* moves = nullptr;    // moves played so far in the game
     int32_t* result = nullptr;   // 2 = running, else black's result {-1,0,1} once finished
@@ -39,7 +45,15 @@ struct Tree {
     float* pi_logits = nullptr;       // [G][A]
     float* val_logits = nullptr;      // [G]
     double* sqrt_tab = nullptr;       // sqrt(i), i <= max_sims + 1, rounded on the host
-    unsigned long long* counters = nullptr;   // [0] leaf evals, [1] transitions
+    unsigned long long* counters = nullptr;   // [0] leaf evals, [1] transitions, [2] errors, [3] states sent through the net
+    // Q mode (mct.py:44-47): per step, the leaf of every game and its valid children form one
+    // compacted evaluation batch: game g owns entries [q_off[g], q_off[g+1]) = leaf, children
+    // in ascending action order
+    int32_t* q_cnt = nullptr;         // [G]
+    int32_t* q_off = nullptr;         // [G+1]
+    uint8_t* q_planes = nullptr;      // [G*(1+A)][6][P]
+    float* q_vals = nullptr;          // [G*(1+A)]
+    int32_t* q_total_host = nullptr;  // pinned
 };
 
 // meta word of a packed state: bits 0..2 flags (go_board.h), bits 8..9 = area sign + 1
@@ -52,6 +66,12 @@ int launch_mcts_backup(int S, const Tree& t, const float* pi_logits, const float
                        int logits_are_raw, hipStream_t st);
 int launch_mcts_readout(int S, const Tree& t, int32_t* visits, double* prior, int32_t* root_visits, hipStream_t st);
 int launch_mcts_policy(int S, const Tree& t, double temp, double* pi, hipStream_t st);
+// Q mode
+int launch_q_scan(const Tree& t, hipStream_t st);
+int launch_q_expand(int S, const Tree& t, uint8_t* children_out, uint8_t* valid_out, hipStream_t st);
+int launch_q_backup(int S, const Tree& t, const double* leaf_val, const double* child_vals_padded, int raw, hipStream_t st);
+int launch_q_child_values(int S, const Tree& t, double* inv_vals, hipStream_t st);
+int launch_q_policy(int S, const Tree& t, double temp, int from_values, double* pi, hipStream_t st);
 int launch_uniform_policy(int S, const Tree& t, int allow_pass, double* pi, hipStream_t st);
 int launch_sample(int S, const Tree& t, const double* pi, uint64_t seed, uint64_t step, int game_offset,
                   int32_t* actions, hipStream_t st);

@@ -30,23 +30,33 @@ int mcts_init(goai_ctx* c, int n_games, int max_sims, int mode)
     GOAI_REQUIRE(n_games > 0, "n_games must be positive");
     // numpy's pairwise mean is maintained incrementally for up to 128 values per node
     GOAI_REQUIRE(max_sims >= 0 && max_sims <= 128, "max_sims must be in [0, 128]");
-    GOAI_REQUIRE(mode == 0, "only the actor-critic search mode (0) is implemented");
+    GOAI_REQUIRE(mode == GOAI_SEARCH_AC || mode == GOAI_SEARCH_Q, "mode must be GOAI_SEARCH_AC or GOAI_SEARCH_Q");
     Tree& t = c->tree;
     t.max_sims = max_sims;
-    t.ncap = max_sims + 2;
+    t.rcap = max_sims + 2;
+    // AC: one new node per step.  Q: every expansion adds up to A children (tree.py:88-98).
+    t.ncap = mode == GOAI_SEARCH_AC ? max_sims + 2 : 2 + (max_sims + 1) * c->A;
     t.mode = mode;
-    const size_t G = n_games, N = G * t.ncap, A = c->A, P = c->P;
+    const size_t G = n_games, N = G * t.ncap, R = G * t.rcap, A = c->A, P = c->P;
     int rc;
 #define AL(field, count) if ((rc = dev_alloc_t(c, &t.field, (count)))) return rc
     AL(st, N * state_words(c->S));
-    AL(parent, N); AL(pact, N); AL(visits, N);
+    AL(parent, N); AL(pact, N); AL(visits, N); AL(rowof, N);
     AL(accR, N * 8); AL(accT, N * 8);
-    AL(prior, N * A); AL(child, N * A); AL(cN, N * A); AL(cQ, N * A);
-    AL(nnodes, G); AL(leaf, G); AL(depth, G); AL(path, N);
+    AL(prior, R * A); AL(child, R * A); AL(cN, R * A); AL(cQ, R * A);
+    AL(nnodes, G); AL(nrows, G); AL(leaf, G); AL(depth, G); AL(path, R);
     AL(turn, G); AL(moves, G); AL(result, G);
     AL(leaf_planes, G * 6 * P); AL(pi_logits, G * A); AL(val_logits, G);
     AL(sqrt_tab, (size_t)max_sims + 2);
     AL(counters, 4);
+    if (mode == GOAI_SEARCH_Q) {
+        AL(nval, N);
+        AL(q_cnt, G); AL(q_off, G + 1);
+        AL(q_planes, G * (1 + A) * 6 * P);
+        AL(q_vals, G * (1 + A));
+        GOAI_HIP_CHECK(hipHostMalloc((void**)&t.q_total_host, sizeof(int32_t), hipHostMallocDefault));
+        c->host_allocs.push_back(t.q_total_host);
+    }
 #undef AL
     std::vector<double> tab(max_sims + 2);
     for (int i = 0; i < max_sims + 2; i++) tab[i] = std::sqrt((double)i);   // IEEE correctly rounded on the host
@@ -71,6 +81,7 @@ int mcts_reset(goai_ctx* c, const uint8_t* roots)
     GOAI_REQUIRE(roots != nullptr, "root_states is NULL");
     c->tree.steps_since_reset = 0;
     c->tree.pending_select = false;
+    c->tree.pending_expand = 0;
     return launch_mcts_reset(c->S, c->tree, roots, c->stream);
 }
 
@@ -84,13 +95,49 @@ int mcts_select(goai_ctx* c, uint8_t* leaf_states_out)
         return GOAI_ERR_STATE;
     }
     t.pending_select = true;
+    t.pending_expand = t.mode == GOAI_SEARCH_Q ? 1 : 0;
     return launch_mcts_select(c->S, t, leaf_states_out, c->stream);
+}
+
+// Q mode, between select and backup: node.make_children() for every non-terminal leaf
+// (mct.py:44-45).  Fills the compacted evaluation batch; optional padded outputs for callers
+// that bring their own value function.
+int mcts_expand(goai_ctx* c, uint8_t* children_out, uint8_t* valid_out)
+{
+    REQUIRE_ROOTS(c);
+    Tree& t = c->tree;
+    GOAI_REQUIRE(t.mode == GOAI_SEARCH_Q, "goai_mcts_expand needs a context initialised with GOAI_SEARCH_Q");
+    if (!t.pending_select || t.pending_expand != 1) {
+        set_error("goai_mcts_expand must follow goai_mcts_select");
+        return GOAI_ERR_STATE;
+    }
+    t.pending_expand = 2;
+    int rc;
+    if ((rc = launch_q_scan(t, c->stream))) return rc;
+    return launch_q_expand(c->S, t, children_out, valid_out, c->stream);
+}
+
+int mcts_backup_q(goai_ctx* c, const double* leaf_val, const double* child_vals, int raw)
+{
+    REQUIRE_ROOTS(c);
+    Tree& t = c->tree;
+    GOAI_REQUIRE(t.mode == GOAI_SEARCH_Q, "goai_mcts_backup_q needs a context initialised with GOAI_SEARCH_Q");
+    if (!t.pending_select || t.pending_expand != 2) {
+        set_error("goai_mcts_backup_q must follow goai_mcts_select and goai_mcts_expand");
+        return GOAI_ERR_STATE;
+    }
+    GOAI_REQUIRE((leaf_val != nullptr) == (child_vals != nullptr), "pass both leaf_val and child_vals, or neither");
+    t.pending_select = false;
+    t.pending_expand = 0;
+    t.steps_since_reset++;
+    return launch_q_backup(c->S, t, leaf_val, child_vals, raw, c->stream);
 }
 
 int mcts_backup(goai_ctx* c, const float* pi_logits, const float* prior, const float* val, int raw)
 {
     REQUIRE_ROOTS(c);
     Tree& t = c->tree;
+    GOAI_REQUIRE(t.mode == GOAI_SEARCH_AC, "goai_mcts_backup is the actor-critic step; use goai_mcts_backup_q");
     if (!t.pending_select) { set_error("goai_mcts_backup without a preceding goai_mcts_select"); return GOAI_ERR_STATE; }
     GOAI_REQUIRE(val != nullptr, "val_logits is NULL");
     GOAI_REQUIRE((pi_logits != nullptr) != (prior != nullptr), "pass exactly one of pi_logits / prior");
@@ -106,8 +153,24 @@ int mcts_steps(goai_ctx* c, int n_steps)
     Tree& t = c->tree;
     GOAI_REQUIRE(n_steps >= 0 && t.steps_since_reset + n_steps <= t.max_sims + 1,
                  "more than max_sims + 1 search steps since the last reset/advance");
-    GOAI_REQUIRE(c->net.loaded && c->net.kind == 0, "an actor-critic network with loaded weights is required");
     int rc;
+    if (t.mode == GOAI_SEARCH_Q) {
+        GOAI_REQUIRE(c->net.loaded, "a network with loaded weights is required");
+        for (int s = 0; s < n_steps; s++) {
+            if ((rc = mcts_select(c, nullptr))) return rc;
+            if ((rc = mcts_expand(c, nullptr, nullptr))) return rc;
+            // the batch size is data dependent (number of legal moves of every leaf)
+            GOAI_HIP_CHECK(hipMemcpyAsync(t.q_total_host, t.q_off + t.n_games, sizeof(int32_t), hipMemcpyDeviceToHost,
+                                          c->stream));
+            GOAI_HIP_CHECK(hipStreamSynchronize(c->stream));
+            const int total = *t.q_total_host;
+            GOAI_REQUIRE(total >= t.n_games && (size_t)total <= (size_t)t.n_games * (1 + c->A), "corrupt batch size");
+            if ((rc = nn_forward_raw(c, t.q_planes, nullptr, t.q_vals, total))) return rc;
+            if ((rc = mcts_backup_q(c, nullptr, nullptr, 1))) return rc;
+        }
+        return GOAI_OK;
+    }
+    GOAI_REQUIRE(c->net.loaded && c->net.kind == 0, "an actor-critic network with loaded weights is required");
     for (int s = 0; s < n_steps; s++) {
         if ((rc = mcts_select(c, nullptr))) return rc;
         if ((rc = nn_forward_raw(c, t.leaf_planes, t.pi_logits, t.val_logits, t.n_games))) return rc;
@@ -122,6 +185,7 @@ int mcts_advance(goai_ctx* c, const int32_t* actions)
     GOAI_REQUIRE(actions != nullptr, "actions is NULL");
     c->tree.steps_since_reset = 0;
     c->tree.pending_select = false;
+    c->tree.pending_expand = 0;
     return launch_mcts_advance(c->S, c->tree, actions, 2 * c->P, c->stream);
 }
 

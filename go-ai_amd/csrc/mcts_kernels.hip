@@ -59,7 +59,9 @@ __global__ __launch_bounds__(64) void k_mcts_reset(Tree t, const uint8_t* __rest
         t.parent[nb] = -1;
         t.pact[nb] = -1;
         t.visits[nb] = 0;
+        t.rowof[nb] = -1;
         t.nnodes[g] = 1;
+        t.nrows[g] = 0;
         t.turn[g] = player;
         t.moves[g] = 0;
         t.result[g] = (flags & FLAG_DONE) ? (player ? -sign : sign) : 2;
@@ -76,8 +78,8 @@ __global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict_
     __shared__ BoardLds<S> L;
     board_init_border<S>(L);
     const int g = blockIdx.x, lane = lane_id();
-    const size_t nb = (size_t)g * t.ncap;
-    int32_t* path = t.path + nb;
+    const size_t nb = (size_t)g * t.ncap, rb = (size_t)g * t.rcap;
+    int32_t* path = t.path + rb;
     int cur = 0, d = 0;
     uint64_t me[G::K], opp[G::K], inv[G::K], meta;
     if (lane == 0) path[0] = 0;
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict_
         node_load<S>(t, nb + cur, me, opp, inv, meta);
         const int N = t.visits[nb + cur];
         if (N == 0 || (meta & FLAG_DONE)) break;
-        const size_t row = (nb + cur) * G::A;
+        const size_t row = (rb + t.rowof[nb + cur]) * G::A;
         const double sqrtN = t.sqrt_tab[N];
         double best = -INFINITY;
         int besta = 0x7fffffff;
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict_
             t.parent[nb + idx] = cur;
             t.pact[nb + idx] = a;
             t.visits[nb + idx] = 0;
+            t.rowof[nb + idx] = -1;
             t.child[row + a] = idx;
             t.nnodes[g] = idx + 1;
             path[d + 1] = idx;
@@ -148,34 +151,40 @@ __global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict_
         t.leaf[g] = cur;
         t.depth[g] = d;
         if (t.result[g] == 2) atomicAdd(&t.counters[0], 1ull);
+        // a non-terminal leaf is expanded by this step's second half: give it its row now
+        const bool expand = !(meta & FLAG_DONE);
+        if (expand && t.rowof[nb + cur] < 0) {
+            const int r = t.nrows[g];
+            if (r < t.rcap) { t.rowof[nb + cur] = r; t.nrows[g] = r + 1; }
+            else atomicAdd(&t.counters[2], 1ull);
+        }
+        if (t.q_cnt) {
+            int nvalid = 1;                        // the pass
+#pragma unroll
+            for (int k = 0; k < G::K; k++) {
+                const int rem = G::P - 64 * k;
+                const uint64_t cells = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+                nvalid += __popcll(~inv[k] & cells);
+            }
+            t.q_cnt[g] = expand ? 1 + nvalid : 1;
+        }
     }
     planes_store<S>(t.leaf_planes + (size_t)g * 6 * G::P, me, opp, inv, 0, (uint32_t)(meta & 7u));
     if (leaf_out) planes_store<S>(leaf_out + (size_t)g * 6 * G::P, me, opp, inv, 0, (uint32_t)(meta & 7u));
 }
 
-// One mct_step, second half: back the leaf value up the path and, for a non-terminal leaf,
-// store its prior.  `prior_in` (fp32, as scipy produced it) bypasses the softmax: that is the
-// "fed the reference's NN outputs" mode of the parity tests.  With `raw` set the logits are
-// straight from the network and RLNet._numpy's post-processing
-// (/root/reference/go_ai/models/__init__.py:90-105) is fused in here.
+// Node.backprop (/root/reference/go_ai/search/tree.py:141-146) for the selected leaf of game g:
+// every node on the path gets tanh(value) with alternating sign appended to its running
+// numpy-pairwise mean, one lane per ancestor; the parent's PUCT inputs (cN, cQ) are refreshed.
 template <int S>
-__global__ __launch_bounds__(64) void k_mcts_backup(Tree t, const float* __restrict__ pi_logits,
-                                                    const float* __restrict__ prior_in,
-                                                    const float* __restrict__ val_in, int raw)
+__device__ __forceinline__ void backprop_path(const Tree& t, int g, double v)
 {
     using G = Geom<S>;
-    const int g = blockIdx.x, lane = lane_id();
-    const size_t nb = (size_t)g * t.ncap;
-    const int leaf = t.leaf[g], d = t.depth[g];
-    const int32_t* path = t.path + nb;
-    uint64_t me[G::K], opp[G::K], inv[G::K], meta;
-    node_load<S>(t, nb + leaf, me, opp, inv, meta);
-    const bool done = meta & FLAG_DONE;
-    const int sign = meta_sign(meta);
-    float v = val_in[g];
-    if (raw && done) v = (float)(100 * sign);
-    const double T = det_tanh64((double)v);
-
+    const int lane = lane_id();
+    const size_t nb = (size_t)g * t.ncap, rb = (size_t)g * t.rcap;
+    const int d = t.depth[g];
+    const int32_t* path = t.path + rb;
+    const double T = det_tanh64(v);
     for (int j = lane; j <= d; j += 64) {
         const int X = path[d - j];
         const size_t xi = nb + X;
@@ -200,14 +209,38 @@ __global__ __launch_bounds__(64) void k_mcts_backup(Tree t, const float* __restr
                 for (int i = 0; i < (n1 & 7); i++) res += Tl[i];
             }
             const double mean = res / (double)n1;
-            const size_t prow = (nb + t.parent[xi]) * G::A + t.pact[xi];
+            const size_t prow = (rb + t.rowof[nb + t.parent[xi]]) * G::A + t.pact[xi];
             t.cN[prow] = n1;
             t.cQ[prow] = -mean;
         }
     }
+}
 
-    if (done) return;
-    const size_t row = (nb + leaf) * G::A;
+// One mct_step, second half: back the leaf value up the path and, for a non-terminal leaf,
+// store its prior.  `prior_in` (fp32, as scipy produced it) bypasses the softmax: that is the
+// "fed the reference's NN outputs" mode of the parity tests.  With `raw` set the logits are
+// straight from the network and RLNet._numpy's post-processing
+// (/root/reference/go_ai/models/__init__.py:90-105) is fused in here.
+template <int S>
+__global__ __launch_bounds__(64) void k_mcts_backup(Tree t, const float* __restrict__ pi_logits,
+                                                    const float* __restrict__ prior_in,
+                                                    const float* __restrict__ val_in, int raw)
+{
+    using G = Geom<S>;
+    const int g = blockIdx.x, lane = lane_id();
+    const size_t nb = (size_t)g * t.ncap, rb = (size_t)g * t.rcap;
+    const int leaf = t.leaf[g];
+    uint64_t me[G::K], opp[G::K], inv[G::K], meta;
+    node_load<S>(t, nb + leaf, me, opp, inv, meta);
+    const bool done = meta & FLAG_DONE;
+    const int sign = meta_sign(meta);
+    float v = val_in[g];
+    if (raw && done) v = (float)(100 * sign);
+    backprop_path<S>(t, g, v);
+
+    const int lrow = t.rowof[nb + leaf];
+    if (done || lrow < 0) return;
+    const size_t row = (rb + lrow) * G::A;
     double pr[G::K];
     if (prior_in) {
 #pragma unroll
@@ -264,8 +297,10 @@ __global__ __launch_bounds__(64) void k_mcts_readout(Tree t, int32_t* __restrict
 {
     using G = Geom<S>;
     const int g = blockIdx.x, lane = lane_id();
-    const size_t nb = (size_t)g * t.ncap, row = nb * G::A;
-    const bool expanded = t.visits[nb] > 0 && !(t.st[nb * G::SW + 3 * G::K] & FLAG_DONE);
+    const size_t nb = (size_t)g * t.ncap;
+    const int rrow = t.rowof[nb];
+    const size_t row = ((size_t)g * t.rcap + (rrow < 0 ? 0 : rrow)) * G::A;
+    const bool expanded = t.visits[nb] > 0 && rrow >= 0 && !(t.st[nb * G::SW + 3 * G::K] & FLAG_DONE);
     for (int a = lane; a < G::A; a += 64) {
         if (visits) visits[(size_t)g * G::A + a] = expanded ? t.cN[row + a] : 0;
         if (prior) prior[(size_t)g * G::A + a] = expanded ? t.prior[row + a] : 0.0;
@@ -285,10 +320,12 @@ __global__ __launch_bounds__(64) void k_mcts_policy(Tree t, double temp, int uni
     __shared__ double buf[G::A];
     __shared__ double total;
     const int g = blockIdx.x, lane = lane_id();
-    const size_t nb = (size_t)g * t.ncap, row = nb * G::A;
+    const size_t nb = (size_t)g * t.ncap;
+    const int rrow = t.rowof[nb];
+    const size_t row = ((size_t)g * t.rcap + (rrow < 0 ? 0 : rrow)) * G::A;
     uint64_t me[G::K], opp[G::K], inv[G::K], meta;
     node_load<S>(t, nb, me, opp, inv, meta);
-    const bool expanded = !uniform_only && t.visits[nb] > 0 && !(meta & FLAG_DONE);
+    const bool expanded = !uniform_only && t.visits[nb] > 0 && rrow >= 0 && !(meta & FLAG_DONE);
     int nvalid = 0;
     bool valid[G::K];
 #pragma unroll
@@ -380,7 +417,9 @@ __global__ __launch_bounds__(64) void k_mcts_advance(Tree t, const int32_t* __re
     }
     if (lane == 0) {
         t.visits[nb] = 0;
+        t.rowof[nb] = -1;
         t.nnodes[g] = 1;
+        t.nrows[g] = 0;
     }
 }
 
@@ -392,6 +431,266 @@ __global__ __launch_bounds__(64) void k_mcts_roots(Tree t, uint8_t* __restrict__
     uint64_t me[G::K], opp[G::K], inv[G::K], meta;
     node_load<S>(t, (size_t)g * t.ncap, me, opp, inv, meta);
     planes_store<S>(states + (size_t)g * 6 * G::P, me, opp, inv, 0, (uint32_t)(meta & 7u));
+}
+
+// ============================================================================================
+// Q-value search (critic mode): mct_step with actor_critic=None
+// (/root/reference/go_ai/search/mct.py:27-30,43-47): the leaf is evaluated, then ALL its valid
+// children are created (Node.make_children, tree.py:88-98), evaluated in one batch
+// (tree.set_state_vals, tree.py:14-19) and the leaf's prior is softmax(-child values) over the
+// valid moves (Node.set_prior_pi(None), tree.py:152-157, fp64).
+// ============================================================================================
+
+// Exclusive scan of the per-game batch sizes -> q_off[0..G]; one 1024-thread workgroup.
+__global__ __launch_bounds__(1024) void k_q_scan(Tree t)
+{
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, G = t.n_games;
+    const int per = (G + 1023) / 1024;
+    const int lo = tid * per, hi = min(G, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; i++) sum += t.q_cnt[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;
+    for (int i = lo; i < hi; i++) { t.q_off[i] = run; run += t.q_cnt[i]; }
+    if (tid == 1023) t.q_off[G] = part[1023];
+}
+
+// rank of action a among the valid actions of a node (ascending action order; the pass is last)
+template <int S>
+__device__ __forceinline__ int valid_rank(const uint64_t* inv, int a)
+{
+    using G = Geom<S>;
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < G::K; k++) {
+        const int lo = 64 * k;
+        const int rem = G::P - lo;
+        const uint64_t cells = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+        uint64_t m = ~inv[k] & cells;
+        if (a < lo + 64) m &= (a <= lo) ? 0ull : (((a - lo) >= 64) ? ~0ull : ((1ull << (a - lo)) - 1ull));
+        r += __popcll(m);
+    }
+    return r;
+}
+
+// One wavefront per (game, action): create the child node of the selected leaf for that action
+// and write its planes into the evaluation batch.  The wave of the pass action also writes the
+// leaf's own planes (entry 0 of the game's slice).  children_out / valid_out (optional) receive
+// GoGame.children(leaf, canonical=True, padded=True) and the valid mask, for callers that
+// evaluate with their own value function.
+template <int S>
+__global__ __launch_bounds__(64) void k_q_expand(Tree t, uint8_t* __restrict__ children_out,
+                                                 uint8_t* __restrict__ valid_out)
+{
+    using G = Geom<S>;
+    __shared__ BoardLds<S> L;
+    board_init_border<S>(L);
+    const long total = (long)t.n_games * G::A;
+    for (long w = blockIdx.x; w < total; w += gridDim.x) {
+        const int g = (int)(w / G::A), a = (int)(w % G::A), lane = lane_id();
+        const size_t nb = (size_t)g * t.ncap, rb = (size_t)g * t.rcap;
+        const int leaf = t.leaf[g];
+        uint64_t me[G::K], opp[G::K], inv[G::K], meta;
+        node_load<S>(t, nb + leaf, me, opp, inv, meta);
+        const bool done = meta & FLAG_DONE;
+        const int off = t.q_off[g];
+        if (a == G::P) planes_store<S>(t.q_planes + (size_t)off * 6 * G::P, me, opp, inv, 0, (uint32_t)(meta & 7u));
+        const int lrow = t.rowof[nb + leaf];
+        const bool valid = !done && lrow >= 0 && ((a == G::P) || !((inv[a >> 6] >> (a & 63)) & 1ull));
+        uint8_t* cout = children_out ? children_out + (size_t)w * 6 * G::P : nullptr;
+        if (valid_out && lane == 0) valid_out[w] = valid ? 1 : 0;
+        if (!valid) {
+            if (lane == 0 && !done && lrow >= 0) t.child[(rb + lrow) * G::A + a] = -1;
+            if (cout) for (int j = lane; j < 6 * G::P; j += 64) cout[j] = 0;
+            continue;
+        }
+        const int j = valid_rank<S>(inv, a);
+        const int idx = t.nnodes[g] + j;        // nnodes is advanced by the backup kernel
+        uint64_t nme[G::K], nopp[G::K], ninv[G::K];
+        uint32_t nflags = 0;
+        int sgn = 0;
+        const int rc = board_next_state<S>(L, me, opp, inv, (uint32_t)(meta & 7u), a, nme, nopp, ninv, nflags, sgn);
+        if (rc != 0 || idx >= t.ncap) {
+            if (lane == 0) { atomicAdd(&t.counters[2], 1ull); t.child[(rb + lrow) * G::A + a] = -1; }
+            __syncthreads();
+            continue;
+        }
+        if (lane == 0) {
+            node_store<S>(t, nb + idx, nme, nopp, ninv, pack_meta(nflags, sgn));
+            t.parent[nb + idx] = leaf;
+            t.pact[nb + idx] = a;
+            t.visits[nb + idx] = 0;
+            t.rowof[nb + idx] = -1;
+            t.child[(rb + lrow) * G::A + a] = idx;
+            atomicAdd(&t.counters[1], 1ull);
+        }
+        planes_store<S>(t.q_planes + (size_t)(off + 1 + j) * 6 * G::P, nme, nopp, ninv, 0, nflags);
+        if (cout) planes_store<S>(cout, nme, nopp, ninv, 0, nflags);
+        __syncthreads();
+    }
+}
+
+// Second half of a critic-mode mct_step.  Values come either from the compacted batch
+// (t.q_vals laid out by t.q_off: the context's own network) or from the caller:
+// leaf_val [G] and child_vals_padded [G][A] float64 (entry a = value of the child reached by
+// action a; the reference keeps val.item(), a Python float, tree.py:14-19).
+// raw != 0: values are straight from the network and RLNet._numpy's override for finished
+// states (/root/reference/go_ai/models/__init__.py:101-105) is applied here.
+template <int S>
+__global__ __launch_bounds__(64) void k_q_backup(Tree t, const double* __restrict__ leaf_val,
+                                                 const double* __restrict__ child_vals_padded, int raw)
+{
+    using G = Geom<S>;
+    const int g = blockIdx.x, lane = lane_id();
+    const size_t nb = (size_t)g * t.ncap, rb = (size_t)g * t.rcap;
+    const int leaf = t.leaf[g];
+    uint64_t me[G::K], opp[G::K], inv[G::K], meta;
+    node_load<S>(t, nb + leaf, me, opp, inv, meta);
+    const bool done = meta & FLAG_DONE;
+    const int off = t.q_off[g];
+    double v = leaf_val ? leaf_val[g] : (double)t.q_vals[off];
+    if (raw && done) v = (double)(100 * meta_sign(meta));
+    backprop_path<S>(t, g, v);
+
+    const int lrow = t.rowof[nb + leaf];
+    if (done || lrow < 0) return;
+    const size_t row = (rb + lrow) * G::A;
+    double q[G::K];
+    bool valid[G::K];
+    double m = -INFINITY;
+    int nvalid = 0;
+#pragma unroll
+    for (int k = 0; k < G::K; k++) {
+        const int a = lane + 64 * k;
+        valid[k] = a < G::A && ((a == G::P) || !((inv[k] >> lane) & 1ull));
+        q[k] = 0.0;
+        int ch = -1;
+        if (valid[k]) ch = t.child[row + a];
+        valid[k] = valid[k] && ch >= 0;
+        if (valid[k]) {
+            double cv = child_vals_padded ? child_vals_padded[(size_t)g * G::A + a]
+                                          : (double)t.q_vals[off + 1 + valid_rank<S>(inv, a)];
+            const uint64_t cmeta = t.st[(nb + ch) * G::SW + 3 * G::K];
+            if (raw && (cmeta & FLAG_DONE)) cv = (double)(100 * meta_sign(cmeta));
+            t.nval[nb + ch] = cv;
+            q[k] = -cv;            // search.invert_vals(child.val), tree.py:128-135
+            m = fmax(m, q[k]);
+        }
+        nvalid += __popcll(__ballot(valid[k]));
+    }
+    m = wave_max_f64(m);
+    double e[G::K], part = 0.0;
+#pragma unroll
+    for (int k = 0; k < G::K; k++) {
+        e[k] = valid[k] ? det_exp64(q[k] - m) : 0.0;
+        part += e[k];
+    }
+    const double sum = wave_sum_f64(part);
+#pragma unroll
+    for (int k = 0; k < G::K; k++) {
+        const int a = lane + 64 * k;
+        if (a < G::A) {
+            t.prior[row + a] = valid[k] ? e[k] / sum : 0.0;
+            t.cN[row + a] = 0;
+            t.cQ[row + a] = 0.0;
+        }
+    }
+    if (lane == 0) {
+        t.nnodes[g] += nvalid;
+        atomicAdd(&t.counters[3], (unsigned long long)(1 + nvalid));
+    }
+}
+
+// rootnode.inverted_children_values() (tree.py:128-135): -child.val, 0 where there is no child.
+template <int S>
+__global__ __launch_bounds__(64) void k_q_child_values(Tree t, double* __restrict__ out)
+{
+    using G = Geom<S>;
+    const int g = blockIdx.x, lane = lane_id();
+    const size_t nb = (size_t)g * t.ncap;
+    const int rrow = t.rowof[nb];
+    const bool expanded = t.visits[nb] > 0 && rrow >= 0 && !(t.st[nb * G::SW + 3 * G::K] & FLAG_DONE);
+    const size_t row = ((size_t)g * t.rcap + (rrow < 0 ? 0 : rrow)) * G::A;
+    for (int a = lane; a < G::A; a += 64) {
+        const int ch = expanded ? t.child[row + a] : -1;
+        out[(size_t)g * G::A + a] = ch >= 0 ? -t.nval[nb + ch] : 0.0;
+    }
+}
+
+// Value.__call__ (/root/reference/go_ai/policies/value.py:30-37), temp > 0:
+//   qs = visit counts (mcts > 0)  |  exp(-child values) (mcts == 0)
+//   pi = search.temp_norm(qs, temp, valid)  (/root/reference/go_ai/search/__init__.py:78-87):
+//        L1-normalise qs over the valid moves, ** (1/temp), L1-normalise over all A entries;
+// the L1 norms are numpy pairwise sums over the COMPACTED valid entries, then over all A.
+// Finished games and unexpanded roots get the uniform-valid distribution.
+template <int S>
+__global__ __launch_bounds__(64) void k_q_policy(Tree t, double temp, int from_values, double* __restrict__ pi)
+{
+    using G = Geom<S>;
+    __shared__ double comp[G::A], full[G::A];
+    __shared__ double total;
+    const int g = blockIdx.x, lane = lane_id();
+    const size_t nb = (size_t)g * t.ncap;
+    const int rrow = t.rowof[nb];
+    const size_t row = ((size_t)g * t.rcap + (rrow < 0 ? 0 : rrow)) * G::A;
+    uint64_t me[G::K], opp[G::K], inv[G::K], meta;
+    node_load<S>(t, nb, me, opp, inv, meta);
+    const bool expanded = t.visits[nb] > 0 && rrow >= 0 && !(meta & FLAG_DONE);
+    bool valid[G::K];
+    double qv[G::K];
+    int rank[G::K];
+    int nvalid = 0;
+#pragma unroll
+    for (int k = 0; k < G::K; k++) {
+        const int a = lane + 64 * k;
+        valid[k] = a < G::A && ((a == G::P) || !((inv[k] >> lane) & 1ull));
+        const uint64_t b = __ballot(valid[k]);
+        rank[k] = nvalid + __popcll(b & ((1ull << lane) - 1ull));
+        nvalid += __popcll(b);
+        qv[k] = 0.0;
+        if (valid[k] && expanded) {
+            if (from_values) {
+                const int ch = t.child[row + a];
+                qv[k] = ch >= 0 ? det_exp64(-t.nval[nb + ch]) : 1.0;
+            } else {
+                qv[k] = (double)t.cN[row + a];
+            }
+        }
+        if (valid[k]) comp[rank[k]] = fabs(qv[k]);
+    }
+    __syncthreads();
+    if (lane == 0) total = np_pairwise_sum(comp, nvalid);
+    __syncthreads();
+    const double s1 = total;
+#pragma unroll
+    for (int k = 0; k < G::K; k++) {
+        const int a = lane + 64 * k;
+        if (a < G::A) {
+            double x = valid[k] ? (s1 != 0.0 ? qv[k] / s1 : qv[k]) : 0.0;
+            if (temp != 1.0) x = pow(x, 1.0 / temp);
+            full[a] = x;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) total = np_pairwise_sum(full, G::A);     // entries are >= 0: |x| = x
+    __syncthreads();
+    const double s2 = total;
+#pragma unroll
+    for (int k = 0; k < G::K; k++) {
+        const int a = lane + 64 * k;
+        if (a < G::A) {
+            const double noise = (valid[k] ? 1.0 : 0.0) / (double)nvalid;
+            pi[(size_t)g * G::A + a] = (expanded && s2 > 0.0) ? full[a] / s2 : noise;
+        }
+    }
 }
 
 // ---- launchers -----------------------------------------------------------------------------
@@ -429,5 +728,32 @@ int launch_mcts_advance(int S_rt, const Tree& t, const int32_t* actions, int max
     LAUNCH_PER_GAME(k_mcts_advance, t, actions, max_moves);
 }
 int launch_mcts_roots(int S_rt, const Tree& t, uint8_t* states, hipStream_t st) { LAUNCH_PER_GAME(k_mcts_roots, t, states); }
+
+int launch_q_scan(const Tree& t, hipStream_t st)
+{
+    k_q_scan<<<dim3(1), dim3(1024), 0, st>>>(t);
+    GOAI_HIP_CHECK(hipGetLastError());
+    return GOAI_OK;
+}
+int launch_q_expand(int S_rt, const Tree& t, uint8_t* children_out, uint8_t* valid_out, hipStream_t st)
+{
+    const long units = (long)t.n_games * (S_rt * S_rt + 1);
+    const int grid = (int)(units < 262144 ? units : 262144);
+    GOAI_DISPATCH_SIZE(S_rt, k_q_expand<S><<<dim3(grid), dim3(64), 0, st>>>(t, children_out, valid_out));
+    GOAI_HIP_CHECK(hipGetLastError());
+    return GOAI_OK;
+}
+int launch_q_backup(int S_rt, const Tree& t, const double* leaf_val, const double* child_vals_padded, int raw, hipStream_t st)
+{
+    LAUNCH_PER_GAME(k_q_backup, t, leaf_val, child_vals_padded, raw);
+}
+int launch_q_child_values(int S_rt, const Tree& t, double* inv_vals, hipStream_t st)
+{
+    LAUNCH_PER_GAME(k_q_child_values, t, inv_vals);
+}
+int launch_q_policy(int S_rt, const Tree& t, double temp, int from_values, double* pi, hipStream_t st)
+{
+    LAUNCH_PER_GAME(k_q_policy, t, temp, from_values, pi);
+}
 
 }  // namespace goai

@@ -42,6 +42,10 @@ _SIGNATURES = {
     "goai_mcts_reset": [c_void_p, c_void_p],
     "goai_mcts_select": [c_void_p, c_void_p],
     "goai_mcts_backup": [c_void_p, c_void_p, c_void_p, c_void_p, c_int],
+    "goai_mcts_expand": [c_void_p, c_void_p, c_void_p],
+    "goai_mcts_backup_q": [c_void_p, c_void_p, c_void_p, c_int],
+    "goai_mcts_child_values": [c_void_p, c_void_p],
+    "goai_mcts_policy_value": [c_void_p, c_double, c_int, c_void_p],
     "goai_mcts_run": [c_void_p, c_int],
     "goai_mcts_steps": [c_void_p, c_int],
     "goai_mcts_readout": [c_void_p, c_void_p, c_void_p, c_void_p],

@@ -120,8 +120,10 @@ class Context:
         return pi, val
 
     # ---- batched search ------------------------------------------------------------
+    SEARCH_AC, SEARCH_Q = 0, 1
+
     def mcts_init(self, n_games, max_sims, mode=0):
-        self.n_games, self.max_sims = int(n_games), int(max_sims)
+        self.n_games, self.max_sims, self.search_mode = int(n_games), int(max_sims), int(mode)
         _hip.check(_hip.lib.goai_mcts_init(self._h, self.n_games, self.max_sims, int(mode)))
 
     def mcts_reset(self, root_states):
@@ -147,6 +149,32 @@ class Context:
         assert val.numel() == self.n_games
         _hip.check(_hip.lib.goai_mcts_backup(self._h, _hip.ptr(pi), _hip.ptr(pr), _hip.ptr(val),
                                              int(bool(logits_are_raw))))
+
+    def mcts_expand(self, want_children=True):
+        """Q mode: make_children of every selected leaf -> (children [G,A,6,s,s], valid [G,A])."""
+        kids = valid = None
+        if want_children:
+            kids = torch.empty((self.n_games, self.A, NUM_CHNLS, self.size, self.size), dtype=torch.uint8,
+                               device=self.device)
+            valid = torch.empty((self.n_games, self.A), dtype=torch.uint8, device=self.device)
+        _hip.check(_hip.lib.goai_mcts_expand(self._h, _hip.ptr(kids), _hip.ptr(valid)))
+        return kids, valid
+
+    def mcts_backup_q(self, leaf_val, child_vals, vals_are_raw=False):
+        lv = torch.as_tensor(leaf_val).to(self.device, dtype=torch.float64).contiguous()
+        cv = torch.as_tensor(child_vals).to(self.device, dtype=torch.float64).contiguous()
+        assert lv.numel() == self.n_games and cv.numel() == self.n_games * self.A
+        _hip.check(_hip.lib.goai_mcts_backup_q(self._h, _hip.ptr(lv), _hip.ptr(cv), int(bool(vals_are_raw))))
+
+    def mcts_child_values(self):
+        out = torch.empty((self.n_games, self.A), dtype=torch.float64, device=self.device)
+        _hip.check(_hip.lib.goai_mcts_child_values(self._h, _hip.ptr(out)))
+        return out
+
+    def mcts_policy_value(self, temp=1.0, from_values=False):
+        pi = torch.empty((self.n_games, self.A), dtype=torch.float64, device=self.device)
+        _hip.check(_hip.lib.goai_mcts_policy_value(self._h, float(temp), int(bool(from_values)), _hip.ptr(pi)))
+        return pi
 
     def mcts_run(self, n_sims):
         _hip.check(_hip.lib.goai_mcts_run(self._h, int(n_sims)))
@@ -191,7 +219,7 @@ class Context:
     def mcts_counters(self):
         out = (ctypes.c_int64 * 4)()
         _hip.check(_hip.lib.goai_mcts_counters(self._h, out))
-        return dict(leaf_evals=out[0], transitions=out[1], errors=out[2])
+        return dict(leaf_evals=out[0], transitions=out[1], errors=out[2], forwards=out[3])
 
     # ---- measurement -----------------------------------------------------------------
     def profile_enable(self, on=True):

@@ -173,7 +173,7 @@ class BatchedSelfPlay:
             self.move()
 
     def counters(self):
-        tot = dict(leaf_evals=0, transitions=0, errors=0)
+        tot = dict(leaf_evals=0, transitions=0, errors=0, forwards=0)
         for c, _ in self._each():
             for k, v in c.mcts_counters().items():
                 tot[k] += v

@@ -95,15 +95,16 @@ class RLNet:
     def to(self, device):
         return self
 
-    def search_context(self, n_games, max_sims):
-        """A context with tree storage for (n_games, max_sims), sharing this net's weights."""
+    def search_context(self, n_games, max_sims, mode=0):
+        """A context with tree storage for (n_games, max_sims, search mode), sharing this net's weights."""
         from ..engine import Context
-        key = (n_games, max_sims)
+        key = (n_games, max_sims, mode)
         if key not in self._search:
             c = Context(self.size, self.device_index)
-            c.nn_init(Context.NET_AC if self.kind == "ac" else Context.NET_VAL, self.layers, max(n_games, 1))
+            batch = n_games if mode == Context.SEARCH_AC else min(n_games * (self.size ** 2 + 2), 16384)
+            c.nn_init(Context.NET_AC if self.kind == "ac" else Context.NET_VAL, self.layers, max(batch, 1))
             c.load_weights(self._sd)
-            c.mcts_init(n_games, max_sims)
+            c.mcts_init(n_games, max_sims, mode)
             self._search[key] = c
         return self._search[key]
 

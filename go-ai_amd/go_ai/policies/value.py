@@ -34,12 +34,18 @@ class Value(Policy):
 
     def __call__(self, go_env, **kwargs):
         debug = kwargs.get('debug', False)
-        state = np.asarray(go_env.canonical_state())
+        from ..search import mct
+        rootnode = mct.mct_search(go_env, self.mcts, critic=self.val_func)
         if self.mcts > 0:
-            raise NotImplementedError("Q-value tree search with mcts > 0 is not available yet")
-        q_logits, rootnode = children_values(state, self.val_func)
-        pi = search.temp_norm(np.exp(q_logits), self.temp, rootnode.valid_moves())
+            qs = rootnode.get_visit_counts()
+            assert np.sum(qs) > 0, rootnode
+        else:
+            qs = np.exp(rootnode.inverted_children_values())
+        # host fp64, as the reference; the batched self-play path has the same normalisation as
+        # a kernel (goai_mcts_policy_value)
+        pi = search.temp_norm(np.asarray(qs, dtype=np.float64), self.temp, rootnode.valid_moves())
         if debug:
+            q_logits = rootnode.inverted_children_values()
             return pi, [q_logits, q_logits], rootnode
         rootnode.destroy()
         return pi

@@ -8,6 +8,11 @@ executed by the GPU-resident tree kernels.
   * any other callable f(states[B,6,s,s]) -> (pi_logits[B,A], val_logits[B,1]) with
     RLNet._numpy semantics (e.g. the reference's torch model): the tree runs on the GPU and f
     is called once per step on the selected leaf (goai_mcts_select / goai_mcts_backup).
+
+`critic` (Q-value search, mct.py:27-30,43-47) works the same way: a create_numpy('critic')
+closure of a go_ai.models net keeps everything on the GPU (leaf + all valid children in one
+compacted batch per step); any other callable f(states[B,6,s,s]) -> val_logits[B,1] is called
+on the leaf and then on its valid children, exactly as tree.set_state_vals does.
 """
 import numpy as np
 
@@ -17,13 +22,42 @@ from .tree import RootView
 _plain_ctx = {}
 
 
-def _tree_context(size, num_searches):
-    key = (size, num_searches)
+def _tree_context(size, num_searches, mode=Context.SEARCH_AC):
+    key = (size, num_searches, mode)
     if key not in _plain_ctx:
         c = Context(size)
-        c.mcts_init(1, num_searches)
+        c.mcts_init(1, num_searches, mode)
         _plain_ctx[key] = c
     return _plain_ctx[key]
+
+
+def _critic_search(root_state, num_searches, critic):
+    size = root_state.shape[-1]
+    net = _owning_net(critic)
+    if net is not None:
+        ctx = net.search_context(1, num_searches, Context.SEARCH_Q)
+        ctx.mcts_reset(root_state[None])
+        ctx.mcts_run(num_searches)
+    else:
+        ctx = _tree_context(size, num_searches, Context.SEARCH_Q)
+        ctx.mcts_reset(root_state[None])
+        for _ in range(num_searches + 1):
+            leaf = ctx.mcts_select().cpu().numpy().astype(np.float64)
+            kids, valid = ctx.mcts_expand()
+            valid = valid[0].cpu().numpy().astype(bool)
+            leaf_val = np.asarray(critic(leaf), dtype=np.float64).reshape(1)
+            child_vals = np.zeros((1, ctx.A), dtype=np.float64)
+            if valid.any():
+                kid_states = kids[0].cpu().numpy()[valid].astype(np.float64)
+                child_vals[0, valid] = np.asarray(critic(kid_states), dtype=np.float64).reshape(-1)
+            ctx.mcts_backup_q(leaf_val, child_vals, vals_are_raw=False)
+    visits, prior, root_visits = ctx.mcts_readout()
+    inv = ctx.mcts_child_values()[0].cpu().numpy()
+    valid_root = np.append(root_state[3].flatten() == 0, True)
+    child_vals = np.where(valid_root, -inv, np.nan)
+    root = RootView(root_state, visits[0].cpu().numpy(), prior[0].cpu().numpy(), root_visits[0].item(), child_vals)
+    root._ctx = ctx
+    return root
 
 
 def _owning_net(fn):
@@ -41,9 +75,10 @@ def _owning_net(fn):
 
 
 def mct_search(go_env, num_searches, actor_critic=None, critic=None):
-    if actor_critic is None:
-        raise NotImplementedError("critic-driven (Q-value) tree search runs through policies.Value")
     root_state = np.asarray(go_env.canonical_state())
+    if actor_critic is None:
+        assert critic is not None
+        return _critic_search(root_state, num_searches, critic)
     size = root_state.shape[-1]
     net = _owning_net(actor_critic)
     if net is not None and net.kind == "ac":

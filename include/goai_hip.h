@@ -117,10 +117,11 @@ int goai_nn_forward(goai_ctx* ctx, const uint8_t* states, float* pi_logits, floa
  * advanced in lock step (one leaf per game per step).
  * ------------------------------------------------------------------------------------- */
 #define GOAI_SEARCH_AC 0   /* mct_search(go_env, n, actor_critic=f), /root/reference/go_ai/search/mct.py:50 */
+#define GOAI_SEARCH_Q 1    /* mct_search(go_env, n, critic=f): Q-value search, mct.py:27-30,43-47 */
 
 /* Allocate tree storage for n_games games and at most max_sims searches per move
  * (max_sims <= 128: numpy's pairwise mean of a node's values, tree.py:180, is maintained
- * incrementally up to 128 entries). */
+ * incrementally up to 128 entries).  mode = GOAI_SEARCH_AC or GOAI_SEARCH_Q. */
 int goai_mcts_init(goai_ctx* ctx, int n_games, int max_sims, int mode);
 
 /* tree.Node(go_env.canonical_state()) for every game (mct.py:52-53): root_states is
@@ -145,8 +146,37 @@ int goai_mcts_select(goai_ctx* ctx, uint8_t* leaf_states_out);
 int goai_mcts_backup(goai_ctx* ctx, const float* pi_logits, const float* prior, const float* val_logits,
                      int logits_are_raw);
 
+/* GOAI_SEARCH_Q only, between goai_mcts_select and goai_mcts_backup_q: node.make_children() for
+ * every non-terminal selected leaf (mct.py:44-45; tree.py:88-98): one child node per valid action
+ * through GoGame.children(state, canonical=True, padded=True).  Optional outputs for callers that
+ * evaluate with their own value function: children_out [n_games][A][6][S][S] (all-zero at
+ * invalid actions and for terminal leaves), valid_out [n_games][A] uint8. */
+int goai_mcts_expand(goai_ctx* ctx, uint8_t* children_out, uint8_t* valid_out);
+
+/* GOAI_SEARCH_Q, second half of mct_step (mct.py:30-37,46-47): node.backprop(val) and, for
+ * non-terminal leaves, tree.set_state_vals(critic, children) + node.set_prior_pi(None), i.e.
+ * prior[valid] = softmax(-child values) in float64 (tree.py:14-19,152-157).
+ * leaf_val [n_games] float64 = critic(leaf.state).item() (the reference keeps Python floats, so a
+ * float64-valued critic such as baselines.greedy_val_func loses nothing); child_vals [n_games][A] float64, entry a =
+ * critic value of the child reached by action a (ignored at invalid actions).  Both NULL: use
+ * the values the context's own network produced for the batch built by goai_mcts_expand
+ * (only inside goai_mcts_run / goai_mcts_steps).  vals_are_raw != 0: RLNet._numpy's override
+ * for finished states (models/__init__.py:101-105) is applied here. */
+int goai_mcts_backup_q(goai_ctx* ctx, const double* leaf_val, const double* child_vals, int vals_are_raw);
+
+/* rootnode.inverted_children_values() (tree.py:128-135) -> [n_games][A] float64: -child.val,
+ * 0 where the root has no child.  GOAI_SEARCH_Q only. */
+int goai_mcts_child_values(goai_ctx* ctx, double* inverted_child_vals);
+
+/* Value.__call__ for temp > 0 (/root/reference/go_ai/policies/value.py:30-37):
+ * pi [n_games][A] float64 = search.temp_norm(qs, temp, valid) (search/__init__.py:78-87) with
+ * qs = root visit counts (from_values == 0, mcts > 0) or exp(-child values) (from_values != 0,
+ * mcts == 0).  Bit-exact for temp == 1.  GOAI_SEARCH_Q only. */
+int goai_mcts_policy_value(goai_ctx* ctx, double temp, int from_values, double* pi);
+
 /* mct_search with the context's own network: 1 + n_sims times select -> forward -> backup
- * (mct.py:55-60; the first iteration "doesn't count"). */
+ * (mct.py:55-60; the first iteration "doesn't count").  In GOAI_SEARCH_Q mode every step
+ * evaluates the leaf and all its valid children in one compacted batch. */
 int goai_mcts_run(goai_ctx* ctx, int n_sims);
 
 /* n_steps x mct_step (select -> forward -> backup) with the context's own network; lets a
@@ -185,7 +215,7 @@ int goai_mcts_roots(goai_ctx* ctx, uint8_t* states, int32_t* turn, int32_t* move
 
 /* Host-side read of 4 counters (synchronises the stream): [0] leaf evaluations of running
  * games, [1] Go transitions made by the search, [2] internal consistency errors (must stay
- * 0), [3] reserved. */
+ * 0), [3] GOAI_SEARCH_Q: states sent through the value network (leaves + children). */
 int goai_mcts_counters(goai_ctx* ctx, int64_t* counters_host);
 
 /* ---------------------------------------------------------------------------------------

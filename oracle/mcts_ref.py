@@ -240,5 +240,11 @@ def actor_critic_policy(go_env, ac_func, mcts, temp, math="numpy"):
 def value_policy(go_env, val_func, mcts, temp, math="numpy"):
     """Value.__call__: visit counts (mcts > 0) or exp(-child values) (mcts == 0) -> temp_norm."""
     root = mct_search(go_env, mcts, critic=val_func, math=math)
-    qs = root.get_visit_counts().astype(float) if mcts > 0 else np.exp(root.inverted_children_values())
+    if mcts > 0:
+        qs = root.get_visit_counts().astype(float)
+    elif math == "det":
+        lib = _det()
+        qs = np.array([lib.goai_oracle_exp64(float(v)) for v in root.inverted_children_values()])
+    else:
+        qs = np.exp(root.inverted_children_values())
     return temp_norm(qs, temp, root.valid_moves()), root

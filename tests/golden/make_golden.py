@@ -207,6 +207,83 @@ def gen_mcts_ac(tag, size, sims, roots, fn_factory, temp=1.0):
     print("wrote", path, "cases", len(cases), "steps", sims + 1)
 
 
+class CriticRecorder:
+    """Wraps a critic callable and records every call (states, values)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+        self.calls = []
+
+    def __call__(self, states):
+        vals = self.fn(states)
+        self.calls.append((np.asarray(states).astype(np.uint8), np.array(vals, dtype=np.float32).reshape(-1)))
+        return vals
+
+
+def fake_critic(style, rng):
+    def fn(states):
+        b = len(states)
+        if style == "flat":             # all-equal values: uniform priors, pure tie-breaking
+            val = np.full((b, 1), -0.125, dtype=np.float32)
+        elif style == "wide":           # spread-out values: peaked softmax(-val) priors
+            val = (rng.standard_normal((b, 1)) * 2.5).astype(np.float32)
+        else:
+            raise ValueError(style)
+        for i, st in enumerate(states):   # same terminal override as RLNet._numpy
+            if ref_data.GoGame.game_ended(st):
+                val[i] = 100 * ref_data.GoGame.winning(st)
+        return val
+    return fn
+
+
+def gen_mcts_q(tag, size, sims, roots, fn_factory, temp=1.0):
+    """Runs the reference's Value policy (critic-driven mct_search inside) from each root."""
+    A = size * size + 1
+    cases = []
+    for ri, root in enumerate(roots):
+        rec = CriticRecorder(fn_factory(ri))
+        args = types.SimpleNamespace(temp=temp, mcts=sims)
+        pol = ref_value.Value("golden", rec, args)
+        env = env_from_state(root)
+        pi, qs, rootnode = pol(env, debug=True)
+        leaf_states, leaf_vals, child_vals, term = [], [], [], []
+        i = 0
+        while i < len(rec.calls):
+            st, v = rec.calls[i]
+            assert len(st) == 1
+            i += 1
+            leaf_states.append(st[0])
+            leaf_vals.append(v[0])
+            ended = bool(og.GoGame.game_ended(st[0]))
+            term.append(ended)
+            cv = np.full(A, np.nan, dtype=np.float32)
+            if not ended:
+                kst, kv = rec.calls[i]
+                i += 1
+                valid = np.flatnonzero(og.GoGame.valid_moves(st[0].astype(np.float64)))
+                assert len(kst) == len(valid), (len(kst), len(valid))
+                kids = og.GoGame.children(st[0].astype(np.float64), canonical=True, padded=True)
+                assert np.array_equal(np.asarray(kids)[valid].astype(np.uint8), kst)
+                cv[valid] = kv
+            child_vals.append(cv)
+        assert len(leaf_states) == sims + 1
+        cases.append(dict(root=np.asarray(og.GoGame.canonical_form(root)).astype(np.uint8),
+                          leaf_states=np.asarray(leaf_states), leaf_vals=np.asarray(leaf_vals, dtype=np.float32),
+                          child_vals=np.asarray(child_vals, dtype=np.float32), terminal=np.asarray(term, dtype=np.uint8),
+                          visits=np.asarray(rootnode.get_visit_counts(), dtype=np.int32),
+                          root_prior=np.asarray(rootnode.prior_pi, dtype=np.float64),
+                          root_visits=np.int32(rootnode.visits),
+                          inv_child_vals=np.asarray(rootnode.inverted_children_values(), dtype=np.float64),
+                          pi=np.asarray(pi, dtype=np.float64)))
+    out = {"n_cases": len(cases), "size": size, "sims": sims, "temp": temp}
+    for i, c in enumerate(cases):
+        for k, v in c.items():
+            out[f"c{i}_{k}"] = v
+    path = os.path.join(HERE, f"mctsq_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "cases", len(cases), "steps", sims + 1)
+
+
 def gen_policy_kat():
     """/root/reference/tests/test_policy.py:34-43 run for real: greedy Value policy, mcts=0."""
     env = og.GoEnv(5)
@@ -224,6 +301,12 @@ def gen_policy_kat():
 
 def main():
     torch.manual_seed(0)
+    only_q = "--only-q" in sys.argv      # add the Q-search fixtures without rewriting the others
+    if only_q:
+        global gen_policy_kat, gen_nn, gen_mcts_ac
+        gen_policy_kat = lambda *a, **k: None
+        gen_nn = lambda *a, **k: None
+        gen_mcts_ac = lambda *a, **k: None
     gen_policy_kat()
     gen_nn("ac", 5, 11, 20)
     gen_nn("ac", 9, 12, 24)
@@ -249,6 +332,19 @@ def main():
     late = [s.astype(np.float64) for s in random_positions(5, 4, 9, min_moves=22, max_moves=40, canonical=False,
                                                            pass_prob=0.2)]
     gen_mcts_ac("ac5_late_n30", 5, 30, late, lambda i: net5.create_numpy("actor_critic"))
+
+    # Q-value searches (Value policy, critic-driven mct_search): real value nets and fake critics
+    val5, _ = ref_net("val", 5, 21)
+    val9, _ = ref_net("val", 9, 13)
+    gen_mcts_q("val5_n0", 5, 0, roots5, lambda i: val5.create_numpy("critic"))
+    gen_mcts_q("val5_n12", 5, 12, roots5, lambda i: val5.create_numpy("critic"))
+    gen_mcts_q("val9_n8", 9, 8, roots9, lambda i: val9.create_numpy("critic"))
+    gen_mcts_q("accrit5_n6", 5, 6, roots5[:3], lambda i: net5.create_numpy("critic"))
+    gen_mcts_q("val5_late_n20", 5, 20, late, lambda i: val5.create_numpy("critic"))
+    for style in ("flat", "wide"):
+        gen_mcts_q(f"fake_{style}5_n30", 5, 30, roots5[:3],
+                   lambda i, style=style: fake_critic(style, np.random.default_rng(300 + i)))
+    gen_mcts_q("fake_wide9_n20", 9, 20, roots9[:2], lambda i: fake_critic("wide", np.random.default_rng(400 + i)))
 
 
 if __name__ == "__main__":

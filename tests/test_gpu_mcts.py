@@ -87,7 +87,7 @@ def test_full_search_matches_oracle(size, n_games, sims):
     visits = c.mcts_readout()[0].cpu().numpy()
     pis = c.mcts_policy(1.0).cpu().numpy()
     assert c.mcts_counters() == dict(leaf_evals=n_games * (sims + 1), transitions=c.mcts_counters()["transitions"],
-                                     errors=0)
+                                     errors=0, forwards=0)
     for g in range(n_games):
         case = dict(leaf_states=[l[g] for l in leaf_log], pi_logits=[p[g] for p in pi_log],
                     val_logits=[v[g, 0] for v in val_log])

@@ -88,3 +88,34 @@ def test_batched_selfplay_runs_games_to_the_end():
     assert st["finished"] == 64 and st["errors"] == 0
     assert st["black_wins"] + st["white_wins"] <= 64
     assert 0 < st["leaf_evals"] <= 64 * 7 * 52
+
+
+def test_value_policy_q_search_matches_golden():
+    """policies.Value with mcts > 0 driven by a host critic (the reference's recorded outputs)."""
+    from golden_util import ReplayCritic
+    from go_ai.env import GoEnv
+    from go_ai.policies.value import Value
+    size, sims, temp, cases = load_mcts("mctsq_val5_n12")
+    for c in cases[:3]:
+        env = GoEnv(size)
+        env.state = c["root"].astype(np.float64)
+        policy = Value("golden", ReplayCritic(c), types.SimpleNamespace(temp=temp, mcts=sims))
+        pi, qs, root = policy(env, debug=True)
+        assert np.array_equal(root.get_visit_counts(), c["visits"]) and root.visits == c["root_visits"]
+        assert np.array_equal(qs[0], c["inv_child_vals"])
+        assert np.array_equal(pi, c["pi"])
+
+
+def test_value_policy_on_gpu_net():
+    from go_ai.env import GoEnv
+    from go_ai.models.val_net import ValueNet
+    from go_ai.policies.value import Value
+    net = ValueNet(5, max_batch=64)
+    policy = Value("v", net, types.SimpleNamespace(temp=1, mcts=6))
+    env = GoEnv(5)
+    env.reset()
+    env.step(12)
+    pi, qs, root = policy(env, debug=True)
+    assert pi.shape == (26,) and abs(pi.sum() - 1) < 1e-12 and pi[12] == 0
+    assert root.get_visit_counts().sum() == 6 and root.visits == 7
+    assert str(policy).startswith("Value[6S 1.00T]")

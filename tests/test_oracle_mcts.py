@@ -3,7 +3,7 @@ reference's own tree.py / mct.py / actorcritic.py (tests/golden/make_golden.py).
 import numpy as np
 import pytest
 
-from golden_util import ReplayNet, load_mcts, mcts_fixture_names
+from golden_util import ReplayCritic, ReplayNet, load_mcts, mcts_fixture_names, mctsq_fixture_names
 from oracle import mcts_ref
 from oracle.gogame import GoEnv, GoGame
 
@@ -37,6 +37,26 @@ def test_deterministic_math_gives_same_visits(oracle_lib, name):
         assert np.array_equal(counts.astype(np.int32), c["visits"])
         assert np.allclose(root.prior_pi, c["root_prior"], rtol=1e-6, atol=1e-9)
         assert np.allclose(pi, c["pi"], rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("name", mctsq_fixture_names())
+@pytest.mark.parametrize("math", ["numpy", "det"])
+def test_oracle_reproduces_reference_q_search(oracle_lib, name, math):
+    """Critic-driven search + Value policy against the reference's own (mct.py:27-47, value.py:19-45)."""
+    size, sims, temp, cases = load_mcts(name)
+    for c in cases:
+        net = ReplayCritic(c)
+        pi, root = mcts_ref.value_policy(_env(c["root"]), net, sims, temp, math=math)
+        assert net.step == sims + 1
+        assert np.array_equal(root.get_visit_counts().astype(np.int32), c["visits"])
+        assert root.visits == c["root_visits"]
+        assert np.array_equal(root.inverted_children_values(), c["inv_child_vals"])
+        if math == "numpy":
+            assert np.array_equal(root.prior_pi, c["root_prior"])
+            assert np.array_equal(pi, c["pi"])
+        else:
+            assert np.allclose(root.prior_pi, c["root_prior"], rtol=1e-12, atol=1e-300)
+            assert np.allclose(pi, c["pi"], rtol=1e-12, atol=0)
 
 
 def test_reference_kat_greedy_obvious_move(oracle_lib):
