@@ -165,9 +165,21 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3(const float* __restrict__ in
     f32x4 a[3];
     a[0] = a_frag(0, tap_off(0), 0, 0);
     a[1] = a_frag(0, tap_off(0), 1 % RT, 1 / RT);
+    // The SIMD arbiter serves the oldest wave first, so of the three workgroups sharing a CU
+    // the first-dispatched one would finish ~30 % early and the last one would run its tail
+    // alone on the SIMD, exposing every LDS latency.  Rotating the issue priority per stage
+    // gives each resident workgroup the same share, so they finish together.
+    const int prio_slot = blockIdx.x / 256;
     for (int s = 0; s < NSTAGE; s++) {
         const int chunk = s / 9, tap = s - chunk * 9;
         const int buf = s & 1;
+#ifndef ABL_NO_PRIO
+        switch ((s + prio_slot) % 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(2); break;
+        }
+#endif
 #ifndef ABL_NO_BLOAD
         if (s + 1 < NSTAGE) load_b(s + 1);
 #endif

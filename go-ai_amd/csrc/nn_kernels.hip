@@ -66,49 +66,113 @@ __global__ __launch_bounds__(256) void k_conv0(const uint8_t* __restrict__ state
 }
 
 // --------------------------------------------------------------------------------------
-// Heads: one 256-thread workgroup per board.
+// Heads: one 256-thread workgroup per HB boards, so that every Linear weight is read once per
+// HB boards instead of once per board (the weights, 136 KB at 9x9, come from L2).
 //   1x1 convs (+ folded BN, ReLU): NC = 3 channels for the actor-critic net (act 0, act 1,
 //   crit) or 1 for the value net; then Linear(2P -> A) and Linear(P -> 256) ReLU Linear(256 -> 1).
+// 1x1 convs: a work item is (board, cell, 16-channel segment); the 8 segments of a cell sit in
+// 8 adjacent lanes (one 512-byte row of the activation tensor per 8 lanes) and are combined
+// by three xor-shuffles.
 // --------------------------------------------------------------------------------------
+constexpr int HB = 4;
+
 template <int S>
 __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ act, HeadWeights hw, int is_ac,
                                                float* __restrict__ pi_out, float* __restrict__ val_out, int nboards)
 {
     using G = Geom<S>;
-    __shared__ float h[3 * G::P];      // [channel][cell]: act0, act1, crit (value net: crit only at h[2P..])
-    __shared__ float z[256];
+    __shared__ float h[HB][3 * G::P];  // [board][channel][cell]: act0, act1, crit (value net: crit only)
+    __shared__ float z[HB][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg = tid & 7;
     const int c_first = is_ac ? 0 : 2;
-    for (int b = blockIdx.x; b < nboards; b += gridDim.x) {
-        __syncthreads();
-        for (int p = wave; p < G::P; p += 4) {
-            const float2 x = *reinterpret_cast<const float2*>(&act[((size_t)b * G::P + p) * 128 + 2 * lane]);
-            for (int c = c_first; c < 3; c++) {
-                const float2 w = *reinterpret_cast<const float2*>(&hw.conv_w[c * 128 + 2 * lane]);
-                float sum = fmaf(x.y, w.y, x.x * w.x);
+    f32x4 w[3][4];
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
-                if (lane == 0) h[c * G::P + p] = fmaxf(sum + hw.conv_b[c], 0.0f);
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            w[c][i] = (c >= c_first) ? *reinterpret_cast<const f32x4*>(&hw.conv_w[c * 128 + seg * 16 + i * 4])
+                                     : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    const float cb[3] = { hw.conv_b[0], hw.conv_b[1], hw.conv_b[2] };
+
+    for (int b0 = blockIdx.x * HB; b0 < nboards; b0 += gridDim.x * HB) {
+        const int nb = min(HB, nboards - b0);
+        __syncthreads();
+        // ---- 1x1 convolutions -> h ----
+        const int items = nb * G::P * 8;
+        for (int it0 = 0; it0 < items; it0 += 256) {
+            const int it = it0 + tid;                 // items is a multiple of 8: a cell's 8 lanes are all in or all out
+            const bool on = it < items;
+            const int cellidx = on ? (it >> 3) : 0;   // = board * P + cell
+            const float* src = act + ((size_t)b0 * G::P + cellidx) * 128 + seg * 16;
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+            if (on) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(src + i * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        s0 = fmaf(x[e], w[0][i][e], s0);
+                        s1 = fmaf(x[e], w[1][i][e], s1);
+                        s2 = fmaf(x[e], w[2][i][e], s2);
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 4; off >= 1; off >>= 1) {
+                s0 += __shfl_xor(s0, off);
+                s1 += __shfl_xor(s1, off);
+                s2 += __shfl_xor(s2, off);
+            }
+            if (on && seg == 0) {
+                const int b = cellidx / G::P, p = cellidx - b * G::P;
+                if (is_ac) {
+                    h[b][p] = fmaxf(s0 + cb[0], 0.0f);
+                    h[b][G::P + p] = fmaxf(s1 + cb[1], 0.0f);
+                }
+                h[b][2 * G::P + p] = fmaxf(s2 + cb[2], 0.0f);
             }
         }
         __syncthreads();
+        // ---- actor: Linear(2P -> A); one thread per output, all boards of the group at once ----
         if (is_ac) {
             for (int a = tid; a < G::A; a += 256) {
-                float sum = hw.act_lin_b[a];
-                for (int j = 0; j < 2 * G::P; j++) sum = fmaf(hw.act_lin_wt[(size_t)j * G::A + a], h[j], sum);
-                pi_out[(size_t)b * G::A + a] = sum;
+                float sum[HB];
+                const float bias = hw.act_lin_b[a];
+#pragma unroll
+                for (int b = 0; b < HB; b++) sum[b] = bias;
+                for (int j = 0; j < 2 * G::P; j++) {
+                    const float wv = hw.act_lin_wt[(size_t)j * G::A + a];
+#pragma unroll
+                    for (int b = 0; b < HB; b++) sum[b] = fmaf(wv, h[b][j], sum[b]);
+                }
+#pragma unroll
+                for (int b = 0; b < HB; b++)
+                    if (b < nb) pi_out[(size_t)(b0 + b) * G::A + a] = sum[b];
             }
         }
+        // ---- critic: Linear(P -> 256) ReLU Linear(256 -> 1) ----
         {
-            float sum = hw.crit_b1[tid];
-            for (int p = 0; p < G::P; p++) sum = fmaf(hw.crit_w1t[p * 256 + tid], h[2 * G::P + p], sum);
-            float v = fmaxf(sum, 0.0f) * hw.crit_w2[tid];
+            float sum[HB];
+            const float bias = hw.crit_b1[tid];
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-            if (lane == 0) z[wave] = v;
+            for (int b = 0; b < HB; b++) sum[b] = bias;
+            for (int p = 0; p < G::P; p++) {
+                const float wv = hw.crit_w1t[p * 256 + tid];
+#pragma unroll
+                for (int b = 0; b < HB; b++) sum[b] = fmaf(wv, h[b][2 * G::P + p], sum[b]);
+            }
+            const float w2 = hw.crit_w2[tid];
+#pragma unroll
+            for (int b = 0; b < HB; b++) {
+                float v = fmaxf(sum[b], 0.0f) * w2;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+                if (lane == 0) z[b][wave] = v;
+            }
         }
         __syncthreads();
-        if (tid == 0) val_out[b] = ((z[0] + z[1]) + (z[2] + z[3])) + hw.crit_b2[0];
+        if (tid < nb) val_out[b0 + tid] = ((z[tid][0] + z[tid][1]) + (z[tid][2] + z[tid][3])) + hw.crit_b2[0];
     }
 }
 
@@ -185,7 +249,8 @@ int launch_conv0(int S_rt, const uint8_t* states, const float* w0, const float* 
 int launch_heads(int S_rt, const float* act, const HeadWeights& hw, int is_ac, float* pi, float* val, int nboards,
                  hipStream_t st)
 {
-    int grid = nboards < 8192 ? nboards : 8192;
+    int groups = (nboards + HB - 1) / HB;
+    int grid = groups < 8192 ? groups : 8192;
     GOAI_DISPATCH_SIZE(S_rt, k_heads<S><<<dim3(grid), dim3(256), 0, st>>>(act, hw, is_ac, pi, val, nboards));
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
