@@ -23,8 +23,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "go-ai_amd"))
 sys.path.insert(0, ROOT)
 
-SIZE, SIMS, GAMES_PER_GPU, LAYERS = 9, 81, 1024, 3
+SIZE, SIMS, GAMES_PER_GPU, LAYERS = 9, 81, 1024, 3      # the default workload: BASELINE.json configs[1]
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, matrix fp32
+
+# The other BASELINE.json configs, runnable with --config for DESIGN.md's tables (the driver's
+# bench line is always c2).  random_moves = upper bound of the random opening length.
+CONFIGS = {
+    "c2": dict(size=9, sims=81, games=1024, layers=3, search="ac", random_moves=40,
+               name="BASELINE.json configs[1]: 9x9 actor-critic (3 blocks x 128 ch), mcts=81/move"),
+    "c3": dict(size=9, sims=8, games=4096, layers=3, search="q", random_moves=40,
+               name="BASELINE.json configs[2]: 9x9 Q-value model, next_states over all 82 actions per leaf + value "
+                    "forward, mcts=8/move"),
+    "c4": dict(size=13, sims=81, games=8192, layers=3, search="ac", random_moves=80,
+               name="BASELINE.json configs[3]: 13x13 actor-critic self-play, mcts=81/move"),
+    "c5": dict(size=19, sims=81, games=4096, layers=10, search="ac", random_moves=250,
+               name="BASELINE.json configs[4]: 19x19 actor-critic, deeper CNN (10 blocks x 128 ch), mcts=81/move"),
+}
 
 
 # --------------------------------------------------------------------------------------
@@ -91,16 +105,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--games", type=int, default=GAMES_PER_GPU)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--games", type=int, default=0, help="games per GPU (default: the config's)")
     ap.add_argument("--groups", type=int, default=1, help="independent game groups on separate HIP streams")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    global SIZE, SIMS, LAYERS
+    SIZE, SIMS, LAYERS = cfg["size"], cfg["sims"], cfg["layers"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "c2":
         cpu = cpu_baseline(args.cpu_seconds)          # before any GPU initialisation
 
     import torch
@@ -116,12 +134,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    n_games = args.games
+    n_games = args.games or cfg["games"]
     sp = BatchedSelfPlay(SIZE, n_games, SIMS, temp=1.0, device=local_rank, n_blocks=LAYERS, seed=1234,
-                         game_id_offset=rank * n_games, groups=args.groups)
-    sp.randomize_starts(40)
+                         game_id_offset=rank * n_games, groups=args.groups, search=cfg["search"])
+    sp.randomize_starts(cfg["random_moves"])
     sp.play(args.warmup)
-    evals0 = sp.counters()["leaf_evals"]
+    cnt0 = sp.counters()
+    evals0 = cnt0["leaf_evals"]
 
     barrier()
     t0 = time.perf_counter()
@@ -135,8 +154,14 @@ def main():
 
     # dominant kernel (conv3x3 implicit GEMM): per-launch duration by HIP events on the
     # kernel's own stream over one more move of the same workload
+    my_forwards = st["forwards"] - cnt0["forwards"]
+    fwd0 = st["forwards"]
     conv_ms, conv_n = sp.profile_conv()
-    conv_flop = 2.0 * (n_games // len(sp.groups) * SIZE * SIZE) * 128 * (9 * 128)
+    if cfg["search"] == "ac":
+        conv_rows = n_games // len(sp.groups) * SIZE * SIZE
+    else:   # data-dependent batch sizes: rows = states sent through the net during the profiled move
+        conv_rows = (sp.counters()["forwards"] - fwd0) * SIZE * SIZE / max(1, conv_n // (2 * LAYERS))
+    conv_flop = 2.0 * conv_rows * 128 * (9 * 128)
     achieved = conv_flop / (conv_ms / conv_n * 1e-3) / 1e12
 
     # the one collective of the run: gather per-rank results (utils.py:201-204's allreduces)
@@ -153,20 +178,19 @@ def main():
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         out = {
-            "metric": "MCTS leaf evals/sec (9x9, transition + NN forward)",
+            "metric": f"MCTS leaf evals/sec ({SIZE}x{SIZE}, transition + NN forward)",
             "value": round(total_evals / t_max, 1),
             "unit": "leaf evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(t_max / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: 9x9 actor-critic (3 blocks x 128 ch), mcts=81/move, "
-                                   f"{n_games} concurrent games per GPU, step = one move of every game "
-                                   "(82 leaf evals per game)",
+            "config": {"workload": f"{cfg['name']}, {n_games} concurrent games per GPU, step = one move of every game "
+                                   f"({SIMS + 1} leaf evals per game)",
                        "board": SIZE, "mcts": SIMS, "games_per_gpu": n_games, "parallelism": f"games sharded x{world}",
                        "stream_groups_per_gpu": len(sp.groups),
                        "weights": "random init, seed 0", "leaf_evals_timed": int(total_evals)},
-            "roofline": {"bound": "mfma", "kernel": "k_conv3x3<9>", "achieved": round(achieved, 2),
+            "roofline": {"bound": "mfma", "kernel": f"k_conv3x3<{SIZE}>", "achieved": round(achieved, 2),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "avg_launch_us": round(conv_ms / conv_n * 1e3, 2), "launches_timed": conv_n,
@@ -175,6 +199,9 @@ def main():
                       "black_wins": int(tot["black_wins"]), "white_wins": int(tot["white_wins"]),
                       "moves_played": int(tot["total_steps"])},
         }
+        if cfg["search"] == "q":
+            out["value_forwards_per_s"] = round(my_forwards / elapsed, 1)
+            out["forwards_per_leaf"] = round(my_forwards / max(1, my_evals), 2)
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 1)

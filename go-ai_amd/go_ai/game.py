@@ -90,13 +90,18 @@ class BatchedSelfPlay:
     them (the groups never exchange data; results do not depend on the grouping)."""
 
     def __init__(self, size, n_games, mcts, temp=1.0, state_dict=None, device=0, n_blocks=3, seed=1234,
-                 game_id_offset=0, groups=1):
+                 game_id_offset=0, groups=1, search="ac", nn_batch=32768):
+        """search = "ac": actor-critic search (ActorCritic policy); "q": Q-value search with the
+        value network (Value policy): every leaf expansion evaluates the leaf and all its valid
+        children, in slices of at most nn_batch states."""
         from .models import random_state_dict
         from .sharding import shard_games
-        self.size, self.n_games, self.mcts, self.temp = size, n_games, mcts, temp
+        assert search in ("ac", "q")
+        self.size, self.n_games, self.mcts, self.temp, self.search = size, n_games, mcts, temp, search
         self.seed, self.game_id_offset = seed, game_id_offset
         groups = max(1, min(groups, n_games))
-        sd = state_dict if state_dict is not None else random_state_dict("ac", size, 0, n_blocks)
+        kind = "ac" if search == "ac" else "val"
+        sd = state_dict if state_dict is not None else random_state_dict(kind, size, 0, n_blocks)
         self.groups = []
         dev = torch.device("cuda", device)
         for gi in range(groups):
@@ -104,9 +109,12 @@ class BatchedSelfPlay:
             stream = torch.cuda.current_stream(dev) if groups == 1 else torch.cuda.Stream(dev)
             c = Context(size, device)
             c.set_stream(stream)
-            c.nn_init(Context.NET_AC, n_blocks, hi - lo)
+            if search == "ac":
+                c.nn_init(Context.NET_AC, n_blocks, hi - lo)
+            else:
+                c.nn_init(Context.NET_VAL, n_blocks, min(nn_batch, (hi - lo) * (size * size + 2)))
             c.load_weights(sd)
-            c.mcts_init(hi - lo, mcts)
+            c.mcts_init(hi - lo, mcts, Context.SEARCH_AC if search == "ac" else Context.SEARCH_Q)
             self.groups.append((c, stream, game_id_offset + lo))
         self.ctx = self.groups[0][0]
         self.move_index = 0
@@ -161,7 +169,7 @@ class BatchedSelfPlay:
                     c.mcts_steps(1)
         out = []
         for c, off in self._each():
-            pi = c.mcts_policy(self.temp)
+            pi = c.mcts_policy(self.temp) if self.search == "ac" else c.mcts_policy_value(self.temp, self.mcts == 0)
             acts = c.sample_actions(pi, self.seed, self.move_index, off)
             c.mcts_advance(acts)
             out.append((pi, acts))

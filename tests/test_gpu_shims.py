@@ -119,3 +119,23 @@ def test_value_policy_on_gpu_net():
     assert pi.shape == (26,) and abs(pi.sum() - 1) < 1e-12 and pi[12] == 0
     assert root.get_visit_counts().sum() == 6 and root.visits == 7
     assert str(policy).startswith("Value[6S 1.00T]")
+
+
+def test_data_batch_helpers_match_oracle():
+    """go_ai.data.batch_* (/root/reference/go_ai/data.py:15-60) against the CPU oracle's rules."""
+    from helpers import random_positions
+    from go_ai import data
+    from oracle.gogame import GoGame as OG
+    states = random_positions(7, 12, seed=5, canonical=True, pass_prob=0.2).astype(np.float64)
+    states[0] = OG.next_state(OG.next_state(states[0], 49, canonical=True), 49, canonical=True)   # a finished game
+    inv = data.batch_invalid_moves(states)
+    assert inv.shape == (12, 50) and (inv[:, -1] == 0).all()
+    assert np.array_equal(data.batch_valid_moves(states), np.stack([OG.valid_moves(s) for s in states]))
+    vals = data.batch_invalid_values(states)
+    assert (vals[inv == 1] == np.finfo(np.float32).min).all() and (vals[inv == 0] == 0).all()
+    kids = data.batch_padded_children(states)
+    want = [np.asarray(OG.children(s, canonical=True, padded=True)) for s in states]
+    assert all(np.array_equal(k, w) for k, w in zip(kids, want))
+    win = data.batch_win_children(kids)
+    want_win = np.array([[OG.winning(c) if OG.game_ended(c) else 0 for c in ch] for ch in want])
+    assert np.array_equal(win, want_win)
