@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 SIZE, SIMS, GAMES_PER_GPU, LAYERS = 9, 81, 1024, 3      # the default workload: BASELINE.json configs[1]
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, matrix fp32
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # same guide, dense bf16; the split path issues 3 bf16 MFMA flops per algorithmic flop
 
 # The other BASELINE.json configs, runnable with --config for DESIGN.md's tables (the driver's
 # bench line is always c2).  random_moves = upper bound of the random opening length.
@@ -107,6 +108,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--games", type=int, default=0, help="games per GPU (default: the config's)")
+    ap.add_argument("--dtype", choices=["f32", "bf16x3"], default="f32",
+                    help="arithmetic of the trunk convolutions: exact fp32 MFMA (default, the reference's precision) "
+                         "or split-operand bf16 MFMA (fp32-grade results, see DESIGN.md)")
     ap.add_argument("--groups", type=int, default=1, help="independent game groups on separate HIP streams")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -136,7 +140,8 @@ def main():
 
     n_games = args.games or cfg["games"]
     sp = BatchedSelfPlay(SIZE, n_games, SIMS, temp=1.0, device=local_rank, n_blocks=LAYERS, seed=1234,
-                         game_id_offset=rank * n_games, groups=args.groups, search=cfg["search"])
+                         game_id_offset=rank * n_games, groups=args.groups, search=cfg["search"],
+                         dtype=1 if args.dtype == "bf16x3" else 0)
     sp.randomize_starts(cfg["random_moves"])
     sp.play(args.warmup)
     cnt0 = sp.counters()
@@ -162,7 +167,8 @@ def main():
     else:   # data-dependent batch sizes: rows = states sent through the net during the profiled move
         conv_rows = (sp.counters()["forwards"] - fwd0) * SIZE * SIZE / max(1, conv_n // (2 * LAYERS))
     conv_flop = 2.0 * conv_rows * 128 * (9 * 128)
-    achieved = conv_flop / (conv_ms / conv_n * 1e-3) / 1e12
+    achieved = conv_flop / (conv_ms / conv_n * 1e-3) / 1e12          # algorithmic flops
+    peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS / 3.0
 
     # the one collective of the run: gather per-rank results (utils.py:201-204's allreduces)
     from go_ai.sharding import gather_stats, reduce_stats
@@ -184,15 +190,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(t_max / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{cfg['name']}, {n_games} concurrent games per GPU, step = one move of every game "
                                    f"({SIMS + 1} leaf evals per game)",
                        "board": SIZE, "mcts": SIMS, "games_per_gpu": n_games, "parallelism": f"games sharded x{world}",
                        "stream_groups_per_gpu": len(sp.groups),
                        "weights": "random init, seed 0", "leaf_evals_timed": int(total_evals)},
-            "roofline": {"bound": "mfma", "kernel": f"k_conv3x3<{SIZE}>", "achieved": round(achieved, 2),
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": f"k_conv3x3{'_bf16' if args.dtype == 'bf16x3' else ''}<{SIZE}>",
+                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic if args.dtype == "f32" else None,
                          "avg_launch_us": round(conv_ms / conv_n * 1e3, 2), "launches_timed": conv_n,
                          "flop_per_launch": conv_flop},
             "games": {"total": int(tot["games"]), "finished": int(tot["finished"]),

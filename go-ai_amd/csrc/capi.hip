@@ -97,8 +97,8 @@ int goai_score(goai_ctx* ctx, const uint8_t* states, int32_t* black_area, int32_
 int goai_nn_init(goai_ctx* ctx, int net_kind, int n_blocks, int max_batch, int dtype)
 {
     CTX_ENTER(ctx);
-    GOAI_REQUIRE(dtype == GOAI_DTYPE_F32, "only GOAI_DTYPE_F32 is implemented");
-    return nn_init(ctx, net_kind, n_blocks, max_batch);
+    GOAI_REQUIRE(dtype == GOAI_DTYPE_F32 || dtype == GOAI_DTYPE_BF16X3, "dtype must be GOAI_DTYPE_F32 or GOAI_DTYPE_BF16X3");
+    return nn_init(ctx, net_kind, n_blocks, max_batch, dtype);
 }
 
 int goai_load_weights(goai_ctx* ctx, const char* const* names, const float* const* tensors_host,

@@ -46,7 +46,7 @@ int launch_score(int S, const uint8_t* states, int32_t* black_area, int32_t* whi
                  int32_t* winner, int n, hipStream_t st);
 
 // ---- CNN (nn_host.hip) ----
-int nn_init(goai_ctx* c, int kind, int layers, int max_batch);
+int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype);
 int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* tensors, const int64_t* numels, int n);
 int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, int n);
 

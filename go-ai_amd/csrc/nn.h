@@ -24,7 +24,9 @@ struct Net {
     float shift = 0.0f;        // input shift: 0.5 for the AC net (ac_net.py:41), 0 for the value net
     float* w0 = nullptr;       // [54][128]   conv0, k = ci*9 + tap
     float* b0 = nullptr;       // [128]
-    float* wt = nullptr;       // [2*layers][4 chunks][9 taps][128 out][32 in]
+    int dtype = 0;             // GOAI_DTYPE_F32 / GOAI_DTYPE_BF16X3: arithmetic of the 3x3 trunk convolutions
+    float* wt = nullptr;       // f32:  [2*layers][4 chunks][9 taps][128 out][32 in]
+    void* wt_bf16 = nullptr;   // bf16x3: [2*layers][4 chunks][9 taps][128 out][32 hi | 32 lo]
     float* bt = nullptr;       // [2*layers][128]
     float* head_blob = nullptr;
     HeadWeights hw{};
@@ -35,6 +37,8 @@ int launch_conv0(int S, const uint8_t* states, const float* w0, const float* b0,
                  int nboards, hipStream_t st);
 int launch_conv3x3(int S, const float* in, const float* wt, const float* bias, const float* resid, float* out, int M,
                    hipStream_t st);
+int launch_conv3x3_bf16(int S, const float* in, const void* wt_bf16, const float* bias, const float* resid, float* out,
+                        int M, hipStream_t st);
 int launch_heads(int S, const float* act, const HeadWeights& hw, int is_ac, float* pi, float* val, int nboards,
                  hipStream_t st);
 int launch_numpy_shim(int S, const uint8_t* states, float* pi, float* val, int n, hipStream_t st);

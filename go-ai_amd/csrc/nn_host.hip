@@ -25,7 +25,18 @@ static int dev_alloc(goai_ctx* c, void** p, size_t bytes)
     return GOAI_OK;
 }
 
-int nn_init(goai_ctx* c, int kind, int layers, int max_batch)
+constexpr size_t WT_BF16_PER_CONV = (size_t)2 * 9 * 128 * 128;   // hi and lo halves
+
+// float -> bfloat16 bits, round to nearest even (what v_cvt_pk_bf16_f32 does on the device)
+static uint16_t bf16_rne(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);   // NaN stays NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
 {
     GOAI_REQUIRE(kind == 0 || kind == 1, "net_kind must be 0 (actor-critic) or 1 (value)");
     GOAI_REQUIRE(layers >= 0 && layers <= 64, "n_blocks out of range");
@@ -35,12 +46,15 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch)
     n.kind = kind;
     n.layers = layers;
     n.max_batch = max_batch;
+    n.dtype = dtype;
     n.shift = kind == 0 ? 0.5f : 0.0f;
     int rc;
     if ((rc = dev_alloc(c, (void**)&n.w0, 54 * 128 * sizeof(float)))) return rc;
     if ((rc = dev_alloc(c, (void**)&n.b0, 128 * sizeof(float)))) return rc;
     if (layers > 0) {
-        if ((rc = dev_alloc(c, (void**)&n.wt, (size_t)2 * layers * 9 * 128 * 128 * sizeof(float)))) return rc;
+        if (dtype == GOAI_DTYPE_BF16X3) {
+            if ((rc = dev_alloc(c, &n.wt_bf16, (size_t)2 * layers * WT_BF16_PER_CONV * sizeof(uint16_t)))) return rc;
+        } else if ((rc = dev_alloc(c, (void**)&n.wt, (size_t)2 * layers * 9 * 128 * 128 * sizeof(float)))) return rc;
         if ((rc = dev_alloc(c, (void**)&n.bt, (size_t)2 * layers * 128 * sizeof(float)))) return rc;
     }
     const size_t P = c->P, A = c->A;
@@ -112,10 +126,34 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
 
     // trunk convs -> [conv][chunk][tap][cout][32 cin]
     std::vector<float> wt((size_t)9 * 128 * 128), bt(128);
+    std::vector<uint16_t> wb(WT_BF16_PER_CONV);
     for (int l = 0; l < 2 * net.layers; l++) {
         const std::string base = "main." + std::to_string(3 + l / 2) + ".main.";
         const std::string conv = base + (l % 2 ? "3" : "0"), bn = base + (l % 2 ? "4" : "1");
         if (!get(m, conv + ".weight", 128 * 128 * 9, w) || !bn_fold(m, conv, bn, 128, sc, sh)) return GOAI_ERR_ARG;
+        for (int co = 0; co < 128; co++) bt[co] = (float)sh[co];
+        GOAI_HIP_CHECK(hipMemcpy(net.bt + (size_t)l * 128, bt.data(), 128 * sizeof(float), hipMemcpyHostToDevice));
+        if (net.dtype == GOAI_DTYPE_BF16X3) {
+            // [4 chunks][9 taps][128 out][32 hi | 32 lo]: BN scale folded in fp64, rounded to fp32 as in the
+            // fp32 path, then split w = hi + lo with hi = bf16(w), lo = bf16(w - hi)
+            for (int chunk = 0; chunk < 4; chunk++)
+                for (int tap = 0; tap < 9; tap++)
+                    for (int co = 0; co < 128; co++)
+                        for (int k = 0; k < 32; k++) {
+                            const int ci = chunk * 32 + k;
+                            const float wf = (float)((double)w[((size_t)co * 128 + ci) * 9 + tap] * sc[co]);
+                            const uint16_t hi = bf16_rne(wf);
+                            uint32_t hu = (uint32_t)hi << 16;
+                            float hf;
+                            memcpy(&hf, &hu, 4);
+                            const size_t base = (((size_t)chunk * 9 + tap) * 128 + co) * 64;
+                            wb[base + k] = hi;
+                            wb[base + 32 + k] = bf16_rne(wf - hf);
+                        }
+            GOAI_HIP_CHECK(hipMemcpy((uint16_t*)net.wt_bf16 + (size_t)l * WT_BF16_PER_CONV, wb.data(),
+                                     wb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            continue;
+        }
         for (int chunk = 0; chunk < 4; chunk++)
             for (int tap = 0; tap < 9; tap++)
                 for (int co = 0; co < 128; co++)
@@ -124,10 +162,8 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
                         wt[(((size_t)chunk * 9 + tap) * 128 + co) * 32 + k] =
                             (float)((double)w[((size_t)co * 128 + ci) * 9 + tap] * sc[co]);
                     }
-        for (int co = 0; co < 128; co++) bt[co] = (float)sh[co];
         GOAI_HIP_CHECK(hipMemcpy(net.wt + (size_t)l * 9 * 128 * 128, wt.data(), wt.size() * sizeof(float),
                                  hipMemcpyHostToDevice));
-        GOAI_HIP_CHECK(hipMemcpy(net.bt + (size_t)l * 128, bt.data(), 128 * sizeof(float), hipMemcpyHostToDevice));
     }
 
     // heads
@@ -169,17 +205,25 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
     return GOAI_OK;
 }
 
-static int timed_conv(goai_ctx* c, const float* in, const float* w, const float* b, const float* resid, float* out,
-                      int M)
+static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const float* resid, float* out, int M)
 {
-    if (!c->prof_enabled) return launch_conv3x3(c->S, in, w, b, resid, out, M, c->stream);
+    const Net& net = c->net;
+    if (net.dtype == GOAI_DTYPE_BF16X3)
+        return launch_conv3x3_bf16(c->S, in, (const uint16_t*)net.wt_bf16 + (size_t)l * WT_BF16_PER_CONV, b, resid, out, M,
+                                   c->stream);
+    return launch_conv3x3(c->S, in, net.wt + (size_t)l * 9 * 128 * 128, b, resid, out, M, c->stream);
+}
+
+static int timed_conv(goai_ctx* c, const float* in, int l, const float* b, const float* resid, float* out, int M)
+{
+    if (!c->prof_enabled) return conv_any(c, in, l, b, resid, out, M);
     hipEvent_t e0, e1;
     GOAI_HIP_CHECK(hipEventCreate(&e0));
     GOAI_HIP_CHECK(hipEventCreate(&e1));
     c->prof_events.push_back(e0);
     c->prof_events.push_back(e1);
     GOAI_HIP_CHECK(hipEventRecord(e0, c->stream));
-    int rc = launch_conv3x3(c->S, in, w, b, resid, out, M, c->stream);
+    int rc = conv_any(c, in, l, b, resid, out, M);
     GOAI_HIP_CHECK(hipEventRecord(e1, c->stream));
     return rc;
 }
@@ -198,10 +242,8 @@ int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, in
             return rc;
         float *x = net.act[0], *y = net.act[1], *z = net.act[2];
         for (int l = 0; l < net.layers; l++) {
-            const float* w1 = net.wt + (size_t)(2 * l) * 9 * 128 * 128;
-            const float* w2 = net.wt + (size_t)(2 * l + 1) * 9 * 128 * 128;
-            if ((rc = timed_conv(c, x, w1, net.bt + (size_t)(2 * l) * 128, nullptr, y, M))) return rc;
-            if ((rc = timed_conv(c, y, w2, net.bt + (size_t)(2 * l + 1) * 128, x, z, M))) return rc;
+            if ((rc = timed_conv(c, x, 2 * l, net.bt + (size_t)(2 * l) * 128, nullptr, y, M))) return rc;
+            if ((rc = timed_conv(c, y, 2 * l + 1, net.bt + (size_t)(2 * l + 1) * 128, x, z, M))) return rc;
             float* t = x; x = z; z = t;
         }
         if ((rc = launch_heads(c->S, x, net.hw, net.kind == 0 && pi != nullptr, pi ? pi + (size_t)done * A : nullptr, val + done, nb,

@@ -91,9 +91,11 @@ class Context:
     NET_AC, NET_VAL = 0, 1
     NN_RAW, NN_NUMPY_SHIM = 0, 1
 
-    def nn_init(self, net_kind, n_blocks=3, max_batch=1024):
+    DTYPE_F32, DTYPE_BF16X3 = 0, 1
+
+    def nn_init(self, net_kind, n_blocks=3, max_batch=1024, dtype=0):
         self.net_kind = int(net_kind)
-        _hip.check(_hip.lib.goai_nn_init(self._h, self.net_kind, int(n_blocks), int(max_batch), 0))
+        _hip.check(_hip.lib.goai_nn_init(self._h, self.net_kind, int(n_blocks), int(max_batch), int(dtype)))
 
     def load_weights(self, state_dict):
         """state_dict: mapping of the reference's keys to float tensors / arrays (host)."""

@@ -90,7 +90,7 @@ class BatchedSelfPlay:
     them (the groups never exchange data; results do not depend on the grouping)."""
 
     def __init__(self, size, n_games, mcts, temp=1.0, state_dict=None, device=0, n_blocks=3, seed=1234,
-                 game_id_offset=0, groups=1, search="ac", nn_batch=32768):
+                 game_id_offset=0, groups=1, search="ac", nn_batch=32768, dtype=Context.DTYPE_F32):
         """search = "ac": actor-critic search (ActorCritic policy); "q": Q-value search with the
         value network (Value policy): every leaf expansion evaluates the leaf and all its valid
         children, in slices of at most nn_batch states."""
@@ -110,9 +110,9 @@ class BatchedSelfPlay:
             c = Context(size, device)
             c.set_stream(stream)
             if search == "ac":
-                c.nn_init(Context.NET_AC, n_blocks, hi - lo)
+                c.nn_init(Context.NET_AC, n_blocks, hi - lo, dtype=dtype)
             else:
-                c.nn_init(Context.NET_VAL, n_blocks, min(nn_batch, (hi - lo) * (size * size + 2)))
+                c.nn_init(Context.NET_VAL, n_blocks, min(nn_batch, (hi - lo) * (size * size + 2)), dtype=dtype)
             c.load_weights(sd)
             c.mcts_init(hi - lo, mcts, Context.SEARCH_AC if search == "ac" else Context.SEARCH_Q)
             self.groups.append((c, stream, game_id_offset + lo))

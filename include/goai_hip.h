@@ -82,7 +82,12 @@ int goai_score(goai_ctx* ctx, const uint8_t* states, int32_t* black_area, int32_
  * ------------------------------------------------------------------------------------- */
 #define GOAI_NET_AC 0       /* ActorCriticNet, /root/reference/go_ai/models/ac_net.py:8-64 */
 #define GOAI_NET_VAL 1      /* ValueNet,       /root/reference/go_ai/models/val_net.py:8-27 */
-#define GOAI_DTYPE_F32 0    /* fp32 storage, fp32 matrix-core accumulate (the reference's precision) */
+#define GOAI_DTYPE_F32 0    /* fp32 storage, exact fp32 matrix-core arithmetic (the reference's precision) */
+#define GOAI_DTYPE_BF16X3 1 /* trunk 3x3 convolutions on the bf16 matrix cores with split operands: every fp32
+                             * activation and weight is split into two bf16 numbers (16 significant bits) and a
+                             * product is hi*hi + lo*hi + hi*lo with fp32 accumulate; activations, residual adds,
+                             * conv0 and the heads stay fp32.  Outputs agree with GOAI_DTYPE_F32 to ~1e-5, i.e.
+                             * inside BASELINE.json's fp32 tolerance of 1e-3 (tests/test_gpu_nn.py) */
 #define GOAI_NN_RAW 0       /* the nn.Module outputs (ac_net.forward / val_net.forward) */
 #define GOAI_NN_NUMPY_SHIM 1 /* + RLNet._numpy post-processing, models/__init__.py:90-105 */
 

@@ -23,10 +23,10 @@ def rel_err(got, want):
     return float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1.0)))
 
 
-def make_ctx(kind, size, seed, layers=3, max_batch=256):
+def make_ctx(kind, size, seed, layers=3, max_batch=256, dtype=0):
     from go_ai.engine import Context
     c = Context(size)
-    c.nn_init(Context.NET_AC if kind == "ac" else Context.NET_VAL, layers, max_batch)
+    c.nn_init(Context.NET_AC if kind == "ac" else Context.NET_VAL, layers, max_batch, dtype=dtype)
     sd = nn_ref.make_state_dict(kind, size, seed, layers)
     c.load_weights(sd)
     return c, sd
@@ -81,6 +81,34 @@ def test_forward_matches_torch_oracle(kind, size, n, layers, max_batch):
     # batch invariance: a state's outputs do not depend on its neighbours in the batch
     k = min(n, 5)
     pi_k, val_k = c.nn_forward(states[:k], mode=c.NN_RAW)
+    assert np.array_equal(val_k.cpu().numpy(), val.cpu().numpy()[:k])
+    c.close()
+
+
+@pytest.mark.parametrize("kind,size,n,layers,max_batch", [
+    ("ac", 9, 333, 3, 128),     # ragged tiles, 3 slices
+    ("ac", 9, 1024, 3, 1024),   # the bench batch
+    ("val", 9, 200, 3, 256),
+    ("ac", 5, 77, 3, 256),
+    ("ac", 13, 50, 3, 64),
+    ("ac", 19, 24, 3, 32),
+    ("ac", 19, 9, 10, 16),      # "deeper CNN": 21 convolutions
+    ("ac", 9, 1, 3, 8),
+])
+def test_bf16x3_forward_within_fp32_tolerance(kind, size, n, layers, max_batch):
+    """GOAI_DTYPE_BF16X3 (split-operand bf16 matrix cores, fp32 accumulate) against the torch fp32
+    oracle at the fp32 tolerance of BASELINE.json (1e-3); expected ~1e-5."""
+    from go_ai.engine import Context
+    c, sd = make_ctx(kind, size, 100 + size + layers, layers, max_batch, dtype=Context.DTYPE_BF16X3)
+    states = random_positions(size, n, seed=size * 7 + n, canonical=True, pass_prob=0.05)
+    want_pi, want_val = nn_ref.forward(sd, torch.tensor(states), kind)
+    pi, val = c.nn_forward(states, mode=c.NN_RAW)
+    ev = rel_err(val.cpu().numpy(), want_val.numpy())
+    ep = rel_err(pi.cpu().numpy(), want_pi.numpy()) if kind == "ac" else 0.0
+    print(f"bf16x3 {kind}{size} L{layers}: rel err val {ev:.2e} pi {ep:.2e}")
+    assert ev < REL_TOL and ep < REL_TOL
+    k = min(n, 5)                 # batch invariance holds here too
+    _, val_k = c.nn_forward(states[:k], mode=c.NN_RAW)
     assert np.array_equal(val_k.cpu().numpy(), val.cpu().numpy()[:k])
     c.close()
 

@@ -18,10 +18,11 @@ ap.add_argument("--size", type=int, default=9)
 ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--layers", type=int, default=3)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--dtype", choices=["f32", "bf16x3"], default="f32")
 args = ap.parse_args()
 
 c = Context(args.size)
-c.nn_init(Context.NET_AC, args.layers, args.batch)
+c.nn_init(Context.NET_AC, args.layers, args.batch, dtype=Context.DTYPE_BF16X3 if args.dtype == "bf16x3" else Context.DTYPE_F32)
 c.load_weights(random_state_dict("ac", args.size, seed=0, layers=args.layers))
 rng = np.random.default_rng(0)
 states = torch.from_numpy((rng.random((args.batch, 6, args.size, args.size)) < 0.3).astype(np.uint8)).cuda()
@@ -37,5 +38,5 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / args.iters
 P = args.size ** 2
 flops = args.batch * (18 * P * (6 * 128 + 2 * args.layers * 128 * 128))
-print(f"size {args.size} batch {args.batch} layers {args.layers}: {ms:.3f} ms/forward, "
+print(f"{args.dtype} size {args.size} batch {args.batch} layers {args.layers}: {ms:.3f} ms/forward, "
       f"{args.batch / ms * 1e3:.0f} boards/s, trunk {flops / ms / 1e9:.1f} TFLOP/s")
