@@ -28,7 +28,8 @@ struct Tree {
     double* accT = nullptr;      // [..][8] pending tail (visits % 8 entries)
     // rows: [G][rcap][A]
     double* prior = nullptr;
-    int32_t* child = nullptr;
+    int32_t* child = nullptr;    // node index of the child; -1 = valid move, no node yet; -2 = invalid move
+    int32_t* crow = nullptr;     // the child's own row (rowof[child]), -1 while it is unvisited or terminal
     int32_t* cN = nullptr;       // child visit counts
     double* cQ = nullptr;        // -mean(tanh(child.post_vals)), 0 while unvisited
     // per game: [G]

@@ -43,7 +43,7 @@ int mcts_init(goai_ctx* c, int n_games, int max_sims, int mode)
     AL(st, N * state_words(c->S));
     AL(parent, N); AL(pact, N); AL(visits, N); AL(rowof, N);
     AL(accR, N * 8); AL(accT, N * 8);
-    AL(prior, R * A); AL(child, R * A); AL(cN, R * A); AL(cQ, R * A);
+    AL(prior, R * A); AL(child, R * A); AL(crow, R * A); AL(cN, R * A); AL(cQ, R * A);
     AL(nnodes, G); AL(nrows, G); AL(leaf, G); AL(depth, G); AL(path, R);
     AL(turn, G); AL(moves, G); AL(result, G);
     AL(leaf_planes, G * 6 * P); AL(pi_logits, G * A); AL(val_logits, G);

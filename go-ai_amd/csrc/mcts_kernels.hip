@@ -70,6 +70,10 @@ __global__ __launch_bounds__(64) void k_mcts_reset(Tree t, const uint8_t* __rest
 
 // One mct_step, first half: descend from the root to the next node to evaluate, creating it
 // (one Go transition) if the chosen edge is new.  Writes the leaf's six input planes.
+// Everything a level of the descent needs sits in the current node's row -- prior, child visit
+// count (= the child's N), cQ, child index (-2 marks an invalid move) and the child's own row
+// (crow, -1 while the child is unvisited or terminal) -- so a level costs ONE round of
+// independent loads, not a chain of node -> visits -> row look-ups.
 template <int S>
 __global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict__ leaf_out)
 {
@@ -81,25 +85,29 @@ __global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict_
     const size_t nb = (size_t)g * t.ncap, rb = (size_t)g * t.rcap;
     int32_t* path = t.path + rb;
     int cur = 0, d = 0;
-    uint64_t me[G::K], opp[G::K], inv[G::K], meta;
+    int N = t.visits[nb];
+    int crow = t.rowof[nb];                  // >= 0 iff the root was expanded (visited and not terminal)
+    long edge = -1;                          // row slot (row * A + action) of the edge into the leaf
+    bool create = false;
+    int act = -1;
     if (lane == 0) path[0] = 0;
-    while (true) {
-        node_load<S>(t, nb + cur, me, opp, inv, meta);
-        const int N = t.visits[nb + cur];
-        if (N == 0 || (meta & FLAG_DONE)) break;
-        const size_t row = (rb + t.rowof[nb + cur]) * G::A;
+    while (crow >= 0) {
+        const size_t row = (rb + crow) * G::A;
         const double sqrtN = t.sqrt_tab[N];
         double best = -INFINITY;
         int besta = 0x7fffffff;
+        int chv[G::K], crv[G::K], nv[G::K];
 #pragma unroll
         for (int k = 0; k < G::K; k++) {
             const int a = lane + 64 * k;
+            chv[k] = -2; crv[k] = -1; nv[k] = 0;
             if (a < G::A) {
-                const bool valid = (a == G::P) || !((inv[k] >> lane) & 1ull);
-                if (valid) {
-                    const double p = t.prior[row + a];
-                    const int n = t.cN[row + a];
-                    const double q = t.cQ[row + a];
+                const int ch = t.child[row + a];
+                const double p = t.prior[row + a];
+                const int n = t.cN[row + a];
+                const double q = t.cQ[row + a];
+                chv[k] = ch; crv[k] = t.crow[row + a]; nv[k] = n;
+                if (ch != -2) {
                     const double u = ((1.5 * p) * sqrtN) / (double)(1 + n);
                     const double ucb = q + u;
                     if (ucb > best) { best = ucb; besta = a; }
@@ -112,40 +120,50 @@ __global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict_
             const int oa = __shfl_xor(besta, off);
             if (ob > best || (ob == best && oa < besta)) { best = ob; besta = oa; }
         }
-        const int a = besta;
-        const int ch = t.child[row + a];
-        if (ch >= 0) {
-            cur = ch;
-            d++;
-            if (lane == 0) path[d] = cur;
-            continue;
-        }
+        const int a = besta, ak = a >> 6;
+        int sch = chv[0], scr = crv[0], sn = nv[0];
+#pragma unroll
+        for (int k = 1; k < G::K; k++)
+            if (ak == k) { sch = chv[k]; scr = crv[k]; sn = nv[k]; }
+        const int ch = __shfl(sch, a & 63), cr = __shfl(scr, a & 63), cn = __shfl(sn, a & 63);
+        edge = (long)(row + a);
+        act = a;
+        if (ch < 0) { create = true; break; }
+        cur = ch;
+        d++;
+        if (lane == 0) path[d] = cur;
+        crow = cr;
+        N = cn;
+    }
+    uint64_t me[G::K], opp[G::K], inv[G::K], meta;
+    node_load<S>(t, nb + cur, me, opp, inv, meta);
+    if (create) {
         uint64_t nme[G::K], nopp[G::K], ninv[G::K];
         uint32_t nflags = 0;
         int sgn = 0;
-        const int rc = board_next_state<S>(L, me, opp, inv, (uint32_t)(meta & 7u), a, nme, nopp, ninv, nflags, sgn);
+        const int rc = board_next_state<S>(L, me, opp, inv, (uint32_t)(meta & 7u), act, nme, nopp, ninv, nflags, sgn);
         const int idx = t.nnodes[g];
         if (rc != 0 || idx >= t.ncap) {          // cannot happen for a consistent tree; never write out of bounds
             if (lane == 0) atomicAdd(&t.counters[2], 1ull);
-            break;
-        }
-        meta = pack_meta(nflags, sgn);
-        if (lane == 0) {
-            node_store<S>(t, nb + idx, nme, nopp, ninv, meta);
-            t.parent[nb + idx] = cur;
-            t.pact[nb + idx] = a;
-            t.visits[nb + idx] = 0;
-            t.rowof[nb + idx] = -1;
-            t.child[row + a] = idx;
-            t.nnodes[g] = idx + 1;
-            path[d + 1] = idx;
-            atomicAdd(&t.counters[1], 1ull);
-        }
+            edge = -1;                           // evaluate the parent again rather than corrupt the tree
+        } else {
+            meta = pack_meta(nflags, sgn);
+            if (lane == 0) {
+                node_store<S>(t, nb + idx, nme, nopp, ninv, meta);
+                t.parent[nb + idx] = cur;
+                t.pact[nb + idx] = act;
+                t.visits[nb + idx] = 0;
+                t.rowof[nb + idx] = -1;
+                t.child[edge] = idx;
+                t.nnodes[g] = idx + 1;
+                path[d + 1] = idx;
+                atomicAdd(&t.counters[1], 1ull);
+            }
 #pragma unroll
-        for (int k = 0; k < G::K; k++) { me[k] = nme[k]; opp[k] = nopp[k]; inv[k] = ninv[k]; }
-        cur = idx;
-        d++;
-        break;
+            for (int k = 0; k < G::K; k++) { me[k] = nme[k]; opp[k] = nopp[k]; inv[k] = ninv[k]; }
+            cur = idx;
+            d++;
+        }
     }
     if (lane == 0) {
         t.leaf[g] = cur;
@@ -155,8 +173,11 @@ __global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict_
         const bool expand = !(meta & FLAG_DONE);
         if (expand && t.rowof[nb + cur] < 0) {
             const int r = t.nrows[g];
-            if (r < t.rcap) { t.rowof[nb + cur] = r; t.nrows[g] = r + 1; }
-            else atomicAdd(&t.counters[2], 1ull);
+            if (r < t.rcap) {
+                t.rowof[nb + cur] = r;
+                t.nrows[g] = r + 1;
+                if (edge >= 0) t.crow[edge] = r;
+            } else atomicAdd(&t.counters[2], 1ull);
         }
         if (t.q_cnt) {
             int nvalid = 1;                        // the pass
@@ -282,8 +303,10 @@ __global__ __launch_bounds__(64) void k_mcts_backup(Tree t, const float* __restr
     for (int k = 0; k < G::K; k++) {
         const int a = lane + 64 * k;
         if (a < G::A) {
+            const bool valid = (a == G::P) || !((inv[k] >> lane) & 1ull);
             t.prior[row + a] = pr[k];
-            t.child[row + a] = -1;
+            t.child[row + a] = valid ? -1 : -2;
+            t.crow[row + a] = -1;
             t.cN[row + a] = 0;
             t.cQ[row + a] = 0.0;
         }
@@ -508,7 +531,7 @@ __global__ __launch_bounds__(64) void k_q_expand(Tree t, uint8_t* __restrict__ c
         uint8_t* cout = children_out ? children_out + (size_t)w * 6 * G::P : nullptr;
         if (valid_out && lane == 0) valid_out[w] = valid ? 1 : 0;
         if (!valid) {
-            if (lane == 0 && !done && lrow >= 0) t.child[(rb + lrow) * G::A + a] = -1;
+            if (lane == 0 && !done && lrow >= 0) t.child[(rb + lrow) * G::A + a] = -2;
             if (cout) for (int j = lane; j < 6 * G::P; j += 64) cout[j] = 0;
             continue;
         }
@@ -519,7 +542,7 @@ __global__ __launch_bounds__(64) void k_q_expand(Tree t, uint8_t* __restrict__ c
         int sgn = 0;
         const int rc = board_next_state<S>(L, me, opp, inv, (uint32_t)(meta & 7u), a, nme, nopp, ninv, nflags, sgn);
         if (rc != 0 || idx >= t.ncap) {
-            if (lane == 0) { atomicAdd(&t.counters[2], 1ull); t.child[(rb + lrow) * G::A + a] = -1; }
+            if (lane == 0) { atomicAdd(&t.counters[2], 1ull); t.child[(rb + lrow) * G::A + a] = -2; }
             __syncthreads();
             continue;
         }
@@ -599,6 +622,7 @@ __global__ __launch_bounds__(64) void k_q_backup(Tree t, const double* __restric
         const int a = lane + 64 * k;
         if (a < G::A) {
             t.prior[row + a] = valid[k] ? e[k] / sum : 0.0;
+            t.crow[row + a] = -1;
             t.cN[row + a] = 0;
             t.cQ[row + a] = 0.0;
         }

@@ -81,7 +81,10 @@ __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ act, He
                                                float* __restrict__ pi_out, float* __restrict__ val_out, int nboards)
 {
     using G = Geom<S>;
+    constexpr int JG = (256 / G::A) > 0 ? (256 / G::A) : 1;       // input slices of the actor Linear
+    constexpr int JLEN = (2 * G::P + JG - 1) / JG;
     __shared__ float h[HB][3 * G::P];  // [board][channel][cell]: act0, act1, crit (value net: crit only)
+    __shared__ float part[JG][HB][G::A];
     __shared__ float z[HB][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seg = tid & 7;
@@ -134,21 +137,32 @@ __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ act, He
             }
         }
         __syncthreads();
-        // ---- actor: Linear(2P -> A); one thread per output, all boards of the group at once ----
+        // ---- actor: Linear(2P -> A): a thread owns (output a, slice jg of the 2P inputs) for all
+        // boards of the group, so that every thread has work and the weight loads of a slice
+        // are independent of one another; the JG partial sums are combined through LDS ----
         if (is_ac) {
-            for (int a = tid; a < G::A; a += 256) {
+            for (int o = tid; o < JG * G::A; o += 256) {
+                const int jg = o / G::A, a = o - jg * G::A;
+                const int j0 = jg * JLEN, j1 = min(2 * G::P, j0 + JLEN);
                 float sum[HB];
-                const float bias = hw.act_lin_b[a];
 #pragma unroll
-                for (int b = 0; b < HB; b++) sum[b] = bias;
-                for (int j = 0; j < 2 * G::P; j++) {
+                for (int b = 0; b < HB; b++) sum[b] = 0.0f;
+#pragma unroll 6
+                for (int j = j0; j < j1; j++) {
                     const float wv = hw.act_lin_wt[(size_t)j * G::A + a];
 #pragma unroll
                     for (int b = 0; b < HB; b++) sum[b] = fmaf(wv, h[b][j], sum[b]);
                 }
 #pragma unroll
-                for (int b = 0; b < HB; b++)
-                    if (b < nb) pi_out[(size_t)(b0 + b) * G::A + a] = sum[b];
+                for (int b = 0; b < HB; b++) part[jg][b][a] = sum[b];
+            }
+            __syncthreads();
+            for (int o = tid; o < nb * G::A; o += 256) {
+                const int b = o / G::A, a = o - b * G::A;
+                float sum = hw.act_lin_b[a];
+#pragma unroll
+                for (int jg = 0; jg < JG; jg++) sum += part[jg][b][a];
+                pi_out[(size_t)(b0 + b) * G::A + a] = sum;
             }
         }
         // ---- critic: Linear(P -> 256) ReLU Linear(256 -> 1) ----
@@ -157,6 +171,7 @@ __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ act, He
             const float bias = hw.crit_b1[tid];
 #pragma unroll
             for (int b = 0; b < HB; b++) sum[b] = bias;
+#pragma unroll 9
             for (int p = 0; p < G::P; p++) {
                 const float wv = hw.crit_w1t[p * 256 + tid];
 #pragma unroll
