@@ -8,6 +8,7 @@
 //   convs.{0,1,4,6}                       value head     (/root/reference/go_ai/models/val_net.py:12-20)
 // game_head.* and *.num_batches_tracked are ignored.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -52,6 +53,11 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
     if ((rc = dev_alloc(c, (void**)&n.w0, 54 * 128 * sizeof(float)))) return rc;
     if ((rc = dev_alloc(c, (void**)&n.b0, 128 * sizeof(float)))) return rc;
     if (layers > 0) {
+        // fp32: Winograd F(2x2,3x3) for boards up to 9x9 (conv_wino_kernels.hip) unless GOAI_CONV_ALGO=direct
+        const char* algo = getenv("GOAI_CONV_ALGO");
+        n.use_wino = dtype == GOAI_DTYPE_F32 && c->S <= 9 && algo && std::string(algo) == "wino";
+        if (n.use_wino && (rc = dev_alloc(c, (void**)&n.wt_wino, (size_t)2 * layers * 16 * 128 * 128 * sizeof(float))))
+            return rc;
         if (dtype == GOAI_DTYPE_BF16X3) {
             if ((rc = dev_alloc(c, &n.wt_bf16, (size_t)2 * layers * WT_BF16_PER_CONV * sizeof(uint16_t)))) return rc;
         } else if ((rc = dev_alloc(c, (void**)&n.wt, (size_t)2 * layers * 9 * 128 * 128 * sizeof(float)))) return rc;
@@ -154,6 +160,25 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
                                      wb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             continue;
         }
+        if (net.use_wino) {
+            // U = G g Gt per (cout, cin), G = (1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1), in fp64, BN scale folded
+            static const double Gm[4][3] = { { 1, 0, 0 }, { 0.5, 0.5, 0.5 }, { 0.5, -0.5, 0.5 }, { 0, 0, 1 } };
+            std::vector<float> wu((size_t)16 * 128 * 128);
+            for (int co = 0; co < 128; co++)
+                for (int ci = 0; ci < 128; ci++) {
+                    const float* g = &w[((size_t)co * 128 + ci) * 9];
+                    for (int pp = 0; pp < 4; pp++)
+                        for (int qq = 0; qq < 4; qq++) {
+                            double u = 0.0;
+                            for (int ky = 0; ky < 3; ky++)
+                                for (int kx = 0; kx < 3; kx++) u += Gm[pp][ky] * Gm[qq][kx] * (double)g[ky * 3 + kx];
+                            const int chunk = ci / 32, k = ci % 32;
+                            wu[((((size_t)chunk * 16 + pp * 4 + qq) * 128) + co) * 32 + k] = (float)(u * sc[co]);
+                        }
+                }
+            GOAI_HIP_CHECK(hipMemcpy(net.wt_wino + (size_t)l * 16 * 128 * 128, wu.data(), wu.size() * sizeof(float),
+                                     hipMemcpyHostToDevice));
+        }
         for (int chunk = 0; chunk < 4; chunk++)
             for (int tap = 0; tap < 9; tap++)
                 for (int co = 0; co < 128; co++)
@@ -211,6 +236,8 @@ static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const f
     if (net.dtype == GOAI_DTYPE_BF16X3)
         return launch_conv3x3_bf16(c->S, in, (const uint16_t*)net.wt_bf16 + (size_t)l * WT_BF16_PER_CONV, b, resid, out, M,
                                    c->stream);
+    if (net.use_wino)
+        return launch_conv3x3_wino(c->S, in, net.wt_wino + (size_t)l * 16 * 128 * 128, b, resid, out, M / c->P, c->stream);
     return launch_conv3x3(c->S, in, net.wt + (size_t)l * 9 * 128 * 128, b, resid, out, M, c->stream);
 }
 

@@ -117,6 +117,31 @@ def test_bf16x3_forward_within_fp32_tolerance(kind, size, n, layers, max_batch, 
     c.close()
 
 
+@pytest.mark.parametrize("kind,size,n,layers,max_batch", [
+    ("ac", 9, 333, 3, 128),     # wtile groups that straddle boards and slices
+    ("ac", 9, 1024, 3, 1024),
+    ("val", 9, 77, 3, 256),
+    ("ac", 7, 50, 3, 64),
+    ("ac", 5, 77, 3, 256),
+    ("ac", 9, 1, 3, 8),
+])
+def test_winograd_forward_matches_torch_oracle(kind, size, n, layers, max_batch, monkeypatch):
+    """GOAI_CONV_ALGO=wino: fp32 Winograd F(2x2,3x3) trunk (conv_wino_kernels.hip), same fp32 bound."""
+    monkeypatch.setenv("GOAI_CONV_ALGO", "wino")
+    c, sd = make_ctx(kind, size, 100 + size + layers, layers, max_batch)
+    monkeypatch.delenv("GOAI_CONV_ALGO")
+    states = random_positions(size, n, seed=size * 7 + n, canonical=True, pass_prob=0.05)
+    want_pi, want_val = nn_ref.forward(sd, torch.tensor(states), kind)
+    pi, val = c.nn_forward(states, mode=c.NN_RAW)
+    assert rel_err(val.cpu().numpy(), want_val.numpy()) < REL_TOL
+    if kind == "ac":
+        assert rel_err(pi.cpu().numpy(), want_pi.numpy()) < REL_TOL
+    k = min(n, 5)
+    _, val_k = c.nn_forward(states[:k], mode=c.NN_RAW)
+    assert np.array_equal(val_k.cpu().numpy(), val.cpu().numpy()[:k])
+    c.close()
+
+
 def test_numpy_shim_matches_oracle_on_special_states():
     from oracle.gogame import GoGame
     c, sd = make_ctx("ac", 5, 11)
