@@ -38,6 +38,7 @@ class Context:
         _hip.check(_hip.lib.goai_ctx_create(ctypes.byref(h), self.device_index, self.size))
         self._h = h
         self.net_kind = -1
+        self.n_games = self.max_sims = self.search_mode = 0
         self.set_stream(torch.cuda.current_stream(self.device))
 
     def close(self):
@@ -125,12 +126,12 @@ class Context:
     SEARCH_AC, SEARCH_Q = 0, 1
 
     def mcts_init(self, n_games, max_sims, mode=0):
+        _hip.check(_hip.lib.goai_mcts_init(self._h, int(n_games), int(max_sims), int(mode)))
         self.n_games, self.max_sims, self.search_mode = int(n_games), int(max_sims), int(mode)
-        _hip.check(_hip.lib.goai_mcts_init(self._h, self.n_games, self.max_sims, int(mode)))
 
     def mcts_reset(self, root_states):
         st = _dev_u8_states(root_states, self.device)
-        assert st.shape == (self.n_games, NUM_CHNLS, self.size, self.size), st.shape
+        assert self.n_games == 0 or st.shape == (self.n_games, NUM_CHNLS, self.size, self.size), st.shape
         _hip.check(_hip.lib.goai_mcts_reset(self._h, _hip.ptr(st)))
 
     def mcts_select(self, want_leaves=True):
