@@ -94,6 +94,15 @@ int goai_score(goai_ctx* ctx, const uint8_t* states, int32_t* black_area, int32_
     return launch_score(ctx->S, states, black_area, white_area, ended, winner, n, ctx->stream);
 }
 
+int goai_liberties(goai_ctx* ctx, const uint8_t* states, int32_t* black_libs, int32_t* white_libs, int n)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return GOAI_OK;
+    GOAI_REQUIRE(states != nullptr, "NULL array argument");
+    return launch_liberties(ctx->S, states, black_libs, white_libs, n, ctx->stream);
+}
+
 int goai_nn_init(goai_ctx* ctx, int net_kind, int n_blocks, int max_batch, int dtype)
 {
     CTX_ENTER(ctx);

@@ -106,6 +106,46 @@ __global__ __launch_bounds__(64) void k_score(const uint8_t* __restrict__ states
     }
 }
 
+// GoGame.get_num_liberties(state) -- /root/reference/go_ai/policies/baselines.py:41: per colour, the
+// number of distinct empty points next to any stone of that colour (planes 0 / 1 as given).
+template <int S>
+__global__ __launch_bounds__(64) void k_liberties(const uint8_t* __restrict__ states, int32_t* __restrict__ black_libs,
+                                                  int32_t* __restrict__ white_libs, int n)
+{
+    using G = Geom<S>;
+    __shared__ BoardLds<S> L;
+    board_init_border<S>(L);
+    const int lane = lane_id();
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint8_t* in = states + (size_t)i * 6 * G::P;
+        uint64_t me[G::K], opp[G::K], inv[G::K];
+        uint32_t flags;
+        const int player = planes_load<S>(in, me, opp, inv, flags);
+        board_load<S>(L, me, opp);
+        int n1 = 0, n2 = 0;                       // empty points next to colour code 1 ("me") / 2 ("opp")
+#pragma unroll
+        for (int k = 0; k < G::K; k++) {
+            const int idx = lane + 64 * k;
+            bool a1 = false, a2 = false;
+            if (idx < G::P) {
+                const int q = cell_q<S>(idx);
+                if (L.col[q] == 0) {
+                    const uint8_t c0 = L.col[q - 1], c1 = L.col[q + 1], c2 = L.col[q - G::PS], c3 = L.col[q + G::PS];
+                    a1 = c0 == 1 || c1 == 1 || c2 == 1 || c3 == 1;
+                    a2 = c0 == 2 || c1 == 2 || c2 == 2 || c3 == 2;
+                }
+            }
+            n1 += __popcll(__ballot(a1));
+            n2 += __popcll(__ballot(a2));
+        }
+        if (lane == 0) {
+            if (black_libs) black_libs[i] = player ? n2 : n1;
+            if (white_libs) white_libs[i] = player ? n1 : n2;
+        }
+        __syncthreads();
+    }
+}
+
 static inline int grid_for(long units) { return (int)(units < 65536 ? (units > 0 ? units : 1) : 65536); }
 
 int launch_transition(int S_rt, const uint8_t* states, const int32_t* actions, int canonical, uint8_t* out,
@@ -122,6 +162,14 @@ int launch_children(int S_rt, const uint8_t* states, int canonical, uint8_t* chi
 {
     if (n <= 0) return GOAI_OK;
     GOAI_DISPATCH_SIZE(S_rt, k_children<S><<<dim3(grid_for((long)n * (S * S + 1))), dim3(64), 0, st>>>(states, canonical, children, valid, win, n));
+    GOAI_HIP_CHECK(hipGetLastError());
+    return GOAI_OK;
+}
+
+int launch_liberties(int S_rt, const uint8_t* states, int32_t* black_libs, int32_t* white_libs, int n, hipStream_t st)
+{
+    if (n <= 0) return GOAI_OK;
+    GOAI_DISPATCH_SIZE(S_rt, k_liberties<S><<<dim3(grid_for(n)), dim3(64), 0, st>>>(states, black_libs, white_libs, n));
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }

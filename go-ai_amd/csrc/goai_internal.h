@@ -45,6 +45,8 @@ int launch_children(int S, const uint8_t* states, int canonical, uint8_t* childr
 int launch_score(int S, const uint8_t* states, int32_t* black_area, int32_t* white_area, int32_t* ended,
                  int32_t* winner, int n, hipStream_t st);
 
+int launch_liberties(int S, const uint8_t* states, int32_t* black_libs, int32_t* white_libs, int n, hipStream_t st);
+
 // ---- CNN (nn_host.hip) ----
 int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype);
 int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* tensors, const int64_t* numels, int n);

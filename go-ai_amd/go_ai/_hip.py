@@ -35,6 +35,7 @@ _SIGNATURES = {
     "goai_transition": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int],
     "goai_children": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int],
     "goai_score": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int],
+    "goai_liberties": [c_void_p, c_void_p, c_void_p, c_void_p, c_int],
     "goai_nn_init": [c_void_p, c_int, c_int, c_int, c_int],
     "goai_load_weights": [c_void_p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), c_int],
     "goai_nn_forward": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int],

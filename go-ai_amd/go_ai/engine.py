@@ -88,6 +88,13 @@ class Context:
         _hip.check(_hip.lib.goai_score(self._h, _hip.ptr(st), *[_hip.ptr(o) for o in outs], n))
         return tuple(outs)   # black_area, white_area, ended, winner
 
+    def liberties(self, states):
+        st = _dev_u8_states(states, self.device)
+        n = st.shape[0]
+        b, w = [torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(2)]
+        _hip.check(_hip.lib.goai_liberties(self._h, _hip.ptr(st), _hip.ptr(b), _hip.ptr(w), n))
+        return b, w
+
     # ---- CNN -----------------------------------------------------------------------
     NET_AC, NET_VAL = 0, 1
     NN_RAW, NN_NUMPY_SHIM = 0, 1

@@ -63,6 +63,11 @@ class GoGame:
         return int(b.item()), int(w.item())
 
     @staticmethod
+    def get_num_liberties(state):
+        b, w = context(state.shape[-1]).liberties(np.asarray(state)[None])
+        return int(b.item()), int(w.item())
+
+    @staticmethod
     def winning(state):
         _, _, _, winner = context(state.shape[-1]).score(np.asarray(state)[None])
         return int(winner.item())

@@ -20,6 +20,21 @@ def greedy_val_func(states):
     return vals[:, np.newaxis]
 
 
+def smart_greedy_val_func(states):
+    # baselines.py:33-55: (6 * area difference + liberty difference) / 7, +-1 / 0 once the game is over
+    if len(states) <= 0:
+        return np.array([])
+    states = np.asarray(states)
+    board_area = states.shape[-1] ** 2
+    c = context(states.shape[-1])
+    b, w, ended, _ = [t.cpu().numpy().astype(np.float64) for t in c.score(states)]
+    bl, wl = [t.cpu().numpy().astype(np.float64) for t in c.liberties(states)]
+    area_val = (b - w) / board_area
+    libs_val = (bl - wl) / board_area
+    vals = np.where(ended > 0, np.sign(b - w), (6 * area_val + libs_val) / 7)
+    return vals[:, np.newaxis]
+
+
 class Random(Policy):
     def __init__(self):
         super().__init__('Random')
@@ -43,6 +58,8 @@ def create_policy(args, name=''):
         return Random(), None
     elif model == 'greedy':
         return Value('Greedy', greedy_val_func, args), greedy_val_func
+    elif model == 'smartgreedy':          # tests/test_pi_v_pi.py:46 asks for it; baselines.py:125 builds it
+        return Value('Smart Greedy', smart_greedy_val_func, args), smart_greedy_val_func
     else:
         raise Exception("Unknown model argument", model)
     load_weights(args, net)

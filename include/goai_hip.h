@@ -77,6 +77,11 @@ int goai_children(goai_ctx* ctx, const uint8_t* states, int canonical, uint8_t* 
 int goai_score(goai_ctx* ctx, const uint8_t* states, int32_t* black_area, int32_t* white_area,
                int32_t* ended, int32_t* winner, int n);
 
+/* GoGame.get_num_liberties(state) for n states (/root/reference/go_ai/policies/baselines.py:41):
+ * per colour, the number of distinct empty points adjacent to a stone of that colour (planes
+ * 0 / 1 as given).  Either output may be NULL. */
+int goai_liberties(goai_ctx* ctx, const uint8_t* states, int32_t* black_libs, int32_t* white_libs, int n);
+
 /* ---------------------------------------------------------------------------------------
  * Policy / value CNN forward
  * ------------------------------------------------------------------------------------- */

@@ -139,3 +139,26 @@ def test_data_batch_helpers_match_oracle():
     win = data.batch_win_children(kids)
     want_win = np.array([[OG.winning(c) if OG.game_ended(c) else 0 for c in ch] for ch in want])
     assert np.array_equal(win, want_win)
+
+
+def test_liberties_and_smart_greedy_match_oracle():
+    """GoGame.get_num_liberties + baselines.smart_greedy_val_func (baselines.py:33-55) vs the oracle."""
+    from helpers import random_positions
+    from go_ai.env import context
+    from go_ai.policies.baselines import greedy_val_func, smart_greedy_val_func
+    from oracle.gogame import GoGame as OG
+    for size in (5, 9, 19):
+        states = random_positions(size, 40, seed=30 + size, max_moves=2 * size * size, canonical=False, pass_prob=0.08)
+        bl, wl = [t.cpu().numpy() for t in context(size).liberties(states)]
+        want = np.array([OG.get_num_liberties(s) for s in states])
+        assert np.array_equal(bl, want[:, 0]) and np.array_equal(wl, want[:, 1])
+        area = size * size
+        wg, ws = [], []
+        for s, (b_l, w_l) in zip(states, want):
+            b, w = OG.areas(s)
+            if OG.game_ended(s):
+                wg.append(100 * np.sign(b - w)); ws.append(np.sign(b - w))
+            else:
+                wg.append((b - w) / area); ws.append((6 * ((b - w) / area) + (b_l - w_l) / area) / 7)
+        assert np.array_equal(greedy_val_func(states)[:, 0], np.array(wg, dtype=float))
+        assert np.array_equal(smart_greedy_val_func(states)[:, 0], np.array(ws, dtype=float))
