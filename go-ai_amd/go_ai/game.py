@@ -118,6 +118,7 @@ class BatchedSelfPlay:
             self.groups.append((c, stream, game_id_offset + lo))
         self.ctx = self.groups[0][0]
         self.move_index = 0
+        self._rec = None
         self.reset()
 
     def _each(self):
@@ -168,13 +169,55 @@ class BatchedSelfPlay:
                 for c, _ in self._each():
                     c.mcts_steps(1)
         out = []
+        rec = []
         for c, off in self._each():
             pi = c.mcts_policy(self.temp) if self.search == "ac" else c.mcts_policy_value(self.temp, self.mcts == 0)
+            if self._rec is not None:
+                states, turn, _, result = c.mcts_roots()
+                rec.append((states, turn, result, pi))
             acts = c.sample_actions(pi, self.seed, self.move_index, off)
             c.mcts_advance(acts)
             out.append((pi, acts))
+        if self._rec is not None:
+            self._rec.append(tuple(torch.cat([r[i] for r in rec]).cpu() for i in range(4))
+                             + (torch.cat([a for _, a in out]).cpu(),))
         self.move_index += 1
         return out
+
+    # ---- trajectories in the reference's replay format (game.py:6-52, data.py:85-105) -------------
+    def record(self, on=True):
+        """Keep (canonical state, side to move, pi, action) of every move so that `trajectories()` can
+        hand the games to the reference's training code."""
+        self._rec = [] if on else None
+
+    def trajectories(self, children_batch=256):
+        """One `Trajectory` per game with the events `game.pit` would have recorded
+        (game.py:80-113): state = canonical state before the move, children =
+        GoGame.children(state, canonical=True, padded=True) (one kernel launch per batch of
+        states), reward 0 except the last = black's result.  Moves of a game that had already
+        finished are dropped.  `won` of an event is from the mover's point of view; games here may
+        start with white to move, so use `trajectory_events` (below) rather than index parity."""
+        assert self._rec is not None, "call record() before playing"
+        final = torch.cat([c.mcts_roots()[3] for c, _ in self._each()]).cpu().numpy()
+        trajs = [Trajectory() for _ in range(self.n_games)]
+        movers = [[] for _ in range(self.n_games)]
+        c0 = self.ctx
+        for states, turn, result, pi, acts in self._rec:
+            live = (result == 2).nonzero().flatten()
+            for lo in range(0, len(live), children_batch):
+                idx = live[lo:lo + children_batch]
+                kids = c0.children(states[idx].to(c0.device), canonical=True)[0].cpu().numpy()
+                for j, g in enumerate(idx.tolist()):
+                    trajs[g].add_event(states[g].numpy().astype(np.float64), int(acts[g]), 0.0,
+                                       kids[j].astype(np.float64), pi[g].numpy())
+                    movers[g].append(int(turn[g]))
+        for g, t in enumerate(trajs):
+            if len(t) > 0:
+                # unfinished games (move cap of this run not reached): winner by the current area score
+                t.set_win(int(final[g]) if final[g] != 2 else 0)
+            t.movers = movers[g]
+        return trajs
+
 
     def play(self, n_moves):
         for _ in range(n_moves):
@@ -212,3 +255,14 @@ class BatchedSelfPlay:
 
 
 from .sharding import STAT_FIELDS, gather_stats, reduce_stats, shard_games  # noqa: E402,F401
+
+
+def trajectory_events(traj):
+    """`Trajectory.get_events()` with the mover taken from the recorded side to move instead of the
+    event index (the reference's games always start with black, game.py:15-24)."""
+    black_won, n, events = traj.get_winner(), len(traj), []
+    movers = getattr(traj, "movers", None)
+    for i, (s, a, r, c, pi) in enumerate(zip(traj.states, traj.actions, traj.rewards, traj.children, traj.pis)):
+        white = movers[i] if movers is not None else i % 2
+        events.append((s, a, r, c, i == n - 1, -black_won if white else black_won, pi))
+    return events

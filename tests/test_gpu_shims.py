@@ -162,3 +162,28 @@ def test_liberties_and_smart_greedy_match_oracle():
                 wg.append((b - w) / area); ws.append((6 * ((b - w) / area) + (b_l - w_l) / area) / 7)
         assert np.array_equal(greedy_val_func(states)[:, 0], np.array(wg, dtype=float))
         assert np.array_equal(smart_greedy_val_func(states)[:, 0], np.array(ws, dtype=float))
+
+
+def test_batched_selfplay_trajectories_replay_on_the_oracle():
+    """BatchedSelfPlay.record()/trajectories(): the recorded (state, action, children) chains are a
+    legal game on the CPU oracle's rules, in the reference's replay layout (game.py:6-52)."""
+    from go_ai.game import BatchedSelfPlay, trajectory_events
+    from oracle.gogame import GoGame as OG
+    sp = BatchedSelfPlay(5, 12, 4, seed=11)
+    sp.randomize_starts(6)
+    sp.record()
+    sp.play(8)
+    trajs = sp.trajectories(children_batch=5)
+    assert len(trajs) == 12 and all(len(t) >= 1 for t in trajs)
+    for t in trajs:
+        for i in range(len(t)):
+            st, a = t.states[i], t.actions[i]
+            assert OG.valid_moves(st)[a] == 1 and abs(t.pis[i].sum() - 1) < 1e-12
+            want = np.asarray(OG.children(st, canonical=True, padded=True))
+            assert np.array_equal(t.children[i], want)
+            if i + 1 < len(t):
+                assert np.array_equal(t.states[i + 1], t.children[i][a])      # game.py:108
+                assert t.rewards[i] == 0
+        ev = trajectory_events(t)
+        assert ev[-1][4] is True and ev[0][3].shape == (26, 6, 5, 5)
+        assert all(e[5] == (-t.get_winner() if m else t.get_winner()) for e, m in zip(ev, t.movers))
