@@ -23,7 +23,7 @@
 //     a zero row;
 //   - the B image (W_tap^T, [128 out][32 hi | 32 lo] = 16 KiB, stored in HBM in this order) is
 //     double-buffered through registers.
-// LDS rows are 128 B (eight 16-byte slots) with the same XOR swizzle as the fp32 kernel.
+// LDS rows are 128 B (eight 16-byte slots), stored in transposed blocks of 16 rows (swz16 below).
 // A workgroup needs <= 79 KiB, so two share a CU (2 waves per SIMD).
 #include <cstdlib>
 
@@ -38,8 +38,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-// index (in 16-byte units) of slot s of row r
-__device__ __forceinline__ int swz16(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
+// LDS images are stored "transposed" in blocks of 16 rows: the 16-byte slot s of rows 16b .. 16b+15
+// is one contiguous 256-byte bank line, so the 16 lanes of a ds_read_b128 lane group -- which
+// always hold 16 consecutive rows, whatever slots their k quarters select -- hit 16 different
+// bank slots for every tap shift (an XOR swizzle of row-major rows conflicts for odd shifts).
+// Index (in 16-byte units) of slot s of row r:
+__device__ __forceinline__ int swz16(int row, int slot) { return (((row >> 4) << 3) + slot) * 16 + (row & 15); }
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b)
 {
@@ -63,14 +67,25 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, uint4& 
     split2(x1[2], x1[3], vh.w, vl.w);
 }
 
+#ifdef GOAI_CONV_STAMPS
+__device__ unsigned long long g_bf_stamps[8 * 4096];   // diagnostic build only: start / loop start / loop end / end
+extern "C" int goai_debug_bf_stamps(unsigned long long* host_out, int n)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_bf_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#define BF_STAMP(i) if (threadIdx.x == 0) g_bf_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define BF_STAMP(i)
+#endif
+
 template <int S, int RTW>
 struct ConvBfCfg {
     static constexpr int BM = 32 * RTW;
     static constexpr int HALO = S + 1;
     static constexpr int ROWS_A = BM + 2 * HALO;               // data rows; row ROWS_A is the zero row
-    static constexpr int A_U4 = (ROWS_A + 1) * 8;
+    static constexpr int A_U4 = ((ROWS_A + 1 + 15) / 16) * 16 * 8;   // whole blocks of 16 rows
     static constexpr int B_U4 = 128 * 8;
-    static constexpr int NA = (ROWS_A * 4 + 255) / 256;        // 8-channel pieces per thread per A chunk
+    static constexpr int NA = (((ROWS_A + 15) / 16) * 64 + 255) / 256;   // 8-channel pieces per thread per A chunk
 };
 
 template <int S, int RTW, bool RESID>
@@ -84,12 +99,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16(const float* __restrict
     uint4* As = lds;
     uint4* Bs = lds + C::A_U4;
 
+    BF_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int m0 = blockIdx.x * C::BM;
     const int li = lane & 15, lq = lane >> 4;
 
-    if (tid < 8) As[C::ROWS_A * 8 + tid] = uint4{ 0u, 0u, 0u, 0u };   // the zero row
+    if (tid < 8) As[swz16(C::ROWS_A, tid)] = uint4{ 0u, 0u, 0u, 0u };   // the zero row
 
     // bit `tap` of vmask[t]: the tap's source cell of row 16*(wr*RTW + t) + li is on the board
     int vmask[RTW];
@@ -115,49 +131,57 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16(const float* __restrict
 #pragma unroll
         for (int ct = 0; ct < 4; ct++) acc[t][ct] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 
-    uint4 breg[4];
-    uint4 areg_h[C::NA], areg_l[C::NA];
+    // raw fp32 pieces of the next chunk's A image; they are split into bf16 halves only when they are
+    // stored (store_a), so the wait for these loads comes after the stage's MFMAs, not before
+    f32x4 araw0[C::NA], araw1[C::NA];
 
     auto load_a = [&](int chunk) {
 #pragma unroll
         for (int i = 0; i < C::NA; i++) {
             const int idx = tid + i * 256;
-            const int row = idx >> 2, piece = idx & 3;
+            const int row = (idx & 15) | ((idx >> 6) << 4), piece = (idx >> 4) & 3;
             const long grow = (long)m0 - C::HALO + row;
-            uint4 vh = { 0u, 0u, 0u, 0u }, vl = { 0u, 0u, 0u, 0u };
+            f32x4 x0 = { 0.0f, 0.0f, 0.0f, 0.0f }, x1 = { 0.0f, 0.0f, 0.0f, 0.0f };
             if (row < C::ROWS_A && grow >= 0 && grow < M) {
                 const float* src = &in[grow * 128 + chunk * 32 + piece * 8];
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(src);
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(src + 4);
-                split8(x0, x1, vh, vl);
+                x0 = *reinterpret_cast<const f32x4*>(src);
+                x1 = *reinterpret_cast<const f32x4*>(src + 4);
             }
-            areg_h[i] = vh;
-            areg_l[i] = vl;
+            araw0[i] = x0;
+            araw1[i] = x1;
         }
     };
     auto store_a = [&]() {
 #pragma unroll
         for (int i = 0; i < C::NA; i++) {
             const int idx = tid + i * 256;
-            const int row = idx >> 2, piece = idx & 3;
+            const int row = (idx & 15) | ((idx >> 6) << 4), piece = (idx >> 4) & 3;
             if (row < C::ROWS_A) {
-                As[swz16(row, piece)] = areg_h[i];
-                As[swz16(row, 4 + piece)] = areg_l[i];
+                uint4 vh, vl;
+                split8(araw0[i], araw1[i], vh, vl);
+                As[swz16(row, piece)] = vh;
+                As[swz16(row, 4 + piece)] = vl;
             }
         }
     };
+    // (four named registers, not an array: hipcc "promotes" a uint4 breg[4] that lives across the
+    // stage into LDS, which turns the prefetch into load -> wait -> LDS -> LDS)
+    const int bsrc0 = ((((tid & 15) | ((tid >> 7) << 4)) << 3) + ((tid >> 4) & 7));     // idx = tid
+    const int bdst0 = swz16((tid & 15) | ((tid >> 7) << 4), (tid >> 4) & 7);
+    uint4 breg0, breg1, breg2, breg3;
     auto load_b = [&](int stage) {
-        const uint4* src = wt + (size_t)stage * C::B_U4;
-#pragma unroll
-        for (int i = 0; i < 4; i++) breg[i] = src[tid + i * 256];
+        const uint4* src = wt + (size_t)stage * C::B_U4 + bsrc0;     // idx = tid + 256 i: rows advance by 32 i
+        breg0 = src[0];
+        breg1 = src[32 * 8];
+        breg2 = src[64 * 8];
+        breg3 = src[96 * 8];
     };
     auto store_b = [&](int buf) {
-        uint4* dst = Bs + buf * C::B_U4;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int idx = tid + i * 256;
-            dst[swz16(idx >> 3, idx & 7)] = breg[i];
-        }
+        uint4* dst = Bs + buf * C::B_U4 + bdst0;                     // 32 rows = 2 blocks of 16 rows = 256 units
+        dst[0] = breg0;
+        dst[256] = breg1;
+        dst[512] = breg2;
+        dst[768] = breg3;
     };
     // A fragments (hi, lo) of this wave's row tile t for the tap whose flat row offset is toff
     auto a_frag = [&](int tap, int toff, int t, bf16x8& hi, bf16x8& lo) {
@@ -177,14 +201,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16(const float* __restrict
     // step i+1 is in flight while step i computes -- across stage boundaries too, as long as the
     // A image stays (same chunk)
     constexpr int NSTAGE = 4 * 9;
+    BF_STAMP(1);
     const int prio_slot = (blockIdx.x / 256) & 1;
     bf16x8 ah[2], al[2];
     a_frag(0, tap_off(0), 0, ah[0], al[0]);
     for (int s = 0; s < NSTAGE; s++) {
         const int chunk = s / 9, tap = s - chunk * 9;
         const int buf = s & 1;
+#ifndef ABL_NOPRIO
         if ((s + prio_slot) & 1) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
+#endif
         if (s + 1 < NSTAGE) load_b(s + 1);
         const bool next_chunk = (tap == 8) && (chunk + 1 < 4);
         if (next_chunk) load_a(chunk + 1);
@@ -212,8 +239,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16(const float* __restrict
 #pragma unroll
             for (int ct = 0; ct < 4; ct++)
                 acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl[ct], acc[t][ct], 0, 0, 0);
+#ifndef ABL_NOSCHED
             __builtin_amdgcn_sched_barrier(0);
+#endif
         }
+        // keep the LDS stores of the next stage's weights BEHIND this stage's MFMAs: left alone, hipcc
+        // hoists them to just after their global loads and exposes the L2 latency in every stage
+        asm volatile("" ::: "memory");
         if (s + 1 < NSTAGE) store_b(buf ^ 1);      // buf^1 was last read in stage s-1
         if (next_chunk) {
             __syncthreads();                        // everyone is done with this chunk's A image
@@ -228,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16(const float* __restrict
         }
     }
     __builtin_amdgcn_s_setprio(0);
+    BF_STAMP(2);
 
     // epilogue.  C/D layout of a 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + reg.
     const bool full = m0 + C::BM <= M;
@@ -266,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16(const float* __restrict
                 }
         }
     }
+    BF_STAMP(3);
 }
 
 // Rows per workgroup = 32 * RTW.  Pick RTW in 3..6 minimising (rounds over the chip's workgroup
