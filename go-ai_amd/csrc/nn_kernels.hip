@@ -66,15 +66,17 @@ __global__ __launch_bounds__(256) void k_conv0(const uint8_t* __restrict__ state
 }
 
 // --------------------------------------------------------------------------------------
-// Heads: one 256-thread workgroup per HB boards, so that every Linear weight is read once per
-// HB boards instead of once per board (the weights, 136 KB at 9x9, come from L2).
+// Heads: one 256-thread workgroup per HB = 2 boards, so that every Linear weight is read once
+// per HB boards instead of once per board (the weights, 136 KB at 9x9, come from L2).  HB = 2
+// measured 16 us at 1024 boards of 9x9 against 45 us for HB = 4: the kernel is latency-bound
+// and more workgroups in flight hide it better than fewer weight reads.
 //   1x1 convs (+ folded BN, ReLU): NC = 3 channels for the actor-critic net (act 0, act 1,
 //   crit) or 1 for the value net; then Linear(2P -> A) and Linear(P -> 256) ReLU Linear(256 -> 1).
 // 1x1 convs: a work item is (board, cell, 16-channel segment); the 8 segments of a cell sit in
 // 8 adjacent lanes (one 512-byte row of the activation tensor per 8 lanes) and are combined
 // by three xor-shuffles.
 // --------------------------------------------------------------------------------------
-constexpr int HB = 4;
+constexpr int HB = 2;
 
 template <int S>
 __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ act, HeadWeights hw, int is_ac,
