@@ -1,7 +1,9 @@
 """The mask / children half of /root/reference/go_ai/data.py:15-60 on the HIP Go-rule kernels.
 
-Same names, argument meaning and return shapes as the reference; the replay / pickle half of
-that file (data.py:85-182) is storage and out of this build's scope.
+Same names, argument meaning and return shapes as the reference.  Of the replay half
+(data.py:63-105) the in-memory conversions are here (symmetries, state+action planes, replay ->
+events -> numpy batches); the pickle files and the MPI sampling (data.py:108-182) are storage and
+out of this build's scope.
 """
 import numpy as np
 
@@ -42,3 +44,49 @@ def batch_win_children(batch_children):
     _, _, ended, winner = context(kids.shape[-1]).score(kids.reshape((b * a,) + kids.shape[2:]))
     win = np.where(ended.cpu().numpy() > 0, winner.cpu().numpy(), 0)
     return win.reshape(b, a)
+
+
+def batch_random_symmetries(states):
+    """A random one of the 8 board symmetries per state (data.py:63-68)."""
+    states = np.asarray(states)
+    assert len(states.shape) == 4
+    return np.array([GoGame.random_symmetry(state) for state in states])
+
+
+def batch_combine_state_actions(states, actions):
+    """[B, 7, s, s]: the state planes plus a one-hot plane of the action (all zero for the pass),
+    data.py:71-82."""
+    states = np.asarray(states)
+    new_shape = np.array(states.shape)
+    new_shape[1] = GoVars.NUM_CHNLS + 1
+    size = new_shape[-1]
+    state_actions = np.zeros(new_shape)
+    state_actions[:, :-1] = states
+    for i, a in enumerate(actions):
+        if a < size ** 2:
+            state_actions[i, -1, a // size, a % size] = 1
+    return state_actions
+
+
+def replay_to_events(replay):
+    """Flatten trajectories (go_ai.game.Trajectory, e.g. BatchedSelfPlay.trajectories()) into the
+    event tuples (state, action, reward, children, terminal, won, pi) of data.py:85-89."""
+    events = []
+    for traj in replay:
+        events.extend(traj.get_events())
+    return events
+
+
+def events_to_numpy(events):
+    """Column arrays with the reference's dtypes (data.py:92-105)."""
+    if len(events) == 0:
+        return [], [], [], [], [], []
+    cols = list(zip(*events))
+    states = np.array(list(cols[0]), dtype=np.float32)
+    actions = np.array(list(cols[1]), dtype=int)
+    rewards = np.array(list(cols[2]), dtype=np.float32).reshape((-1,))
+    next_states = np.array(list(cols[3]), dtype=np.float32)
+    terminals = np.array(list(cols[4]), dtype=np.uint8)
+    wins = np.array(list(cols[5]), dtype=int)
+    pis = np.array(list(cols[6]), dtype=np.float32)
+    return states, actions, rewards, next_states, terminals, wins, pis

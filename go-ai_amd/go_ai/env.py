@@ -41,7 +41,16 @@ class GoGame:
         return out[0].cpu().numpy().astype(np.float64)
 
     @staticmethod
-    def children(state, canonical=False, padded=True):
+    def children(state, group_map=None, canonical=False, padded=None):
+        """All A next states.  The reference calls this two ways: keywords only, padded=True
+        (tree.py:92, data.py:58) and with GymGo's group_map as second positional argument and no
+        `padded`, expecting the valid children only, in ascending action order
+        (search/__init__.py:14).  group_map was a host-side cache of GymGo's; the kernel
+        recomputes groups, so it is accepted and ignored."""
+        if isinstance(group_map, (bool, np.bool_)):          # children(state, canonical[, padded]) by position
+            group_map, canonical, padded = None, bool(group_map), (True if padded is None else padded)
+        if padded is None:
+            padded = False
         c = context(state.shape[-1])
         kids, valid, _ = c.children(np.asarray(state)[None], canonical)
         kids = kids[0].cpu().numpy().astype(np.float64)
@@ -85,6 +94,33 @@ class GoGame:
         return state
 
     @staticmethod
+    def action_2d_to_1d(action2d, state):
+        size = state.shape[-1]
+        if action2d is None:
+            return size * size
+        return int(action2d[0]) * size + int(action2d[1])
+
+    @staticmethod
+    def get_symmetries(chunk):
+        """The 8 symmetries of a [C, s, s] chunk (views): bit 0 flips rows, bit 1 flips columns,
+        bit 2 rotates a quarter turn (data.py:67, measurements.py:190 use them for augmentation)."""
+        syms = []
+        for i in range(8):
+            x = np.asarray(chunk)
+            if i & 1:
+                x = np.flip(x, 1)
+            if i & 2:
+                x = np.flip(x, 2)
+            if i & 4:
+                x = np.rot90(x, 1, axes=(1, 2))
+            syms.append(x)
+        return syms
+
+    @staticmethod
+    def random_symmetry(chunk):
+        return GoGame.get_symmetries(chunk)[np.random.randint(8)]
+
+    @staticmethod
     def random_weighted_action(move_weights):
         p = np.asarray(move_weights, dtype=np.float64)
         return int(np.random.choice(len(p), p=p / np.sum(p)))
@@ -124,7 +160,7 @@ class GoEnv:
         return GoGame.winning(self.state)
 
     def children(self, canonical=False, padded=True):
-        return GoGame.children(self.state, canonical, padded)
+        return GoGame.children(self.state, canonical=canonical, padded=padded)
 
     def step(self, action):
         assert not self.done

@@ -187,3 +187,52 @@ def test_batched_selfplay_trajectories_replay_on_the_oracle():
         ev = trajectory_events(t)
         assert ev[-1][4] is True and ev[0][3].shape == (26, 6, 5, 5)
         assert all(e[5] == (-t.get_winner() if m else t.get_winner()) for e, m in zip(ev, t.movers))
+
+
+def test_q_helpers_and_replay_conversions_match_oracle():
+    """search.qs_from_valfunc / batchqs_from_valfunc / batch_greedy_pi / batch_temperate_pi
+    (/root/reference/go_ai/search/__init__.py:13-61,90-97) and data.replay_to_events /
+    events_to_numpy / batch_combine_state_actions / batch_random_symmetries (data.py:63-105)."""
+    from helpers import random_positions
+    from go_ai import data, search
+    from go_ai.env import GoGame
+    from go_ai.game import BatchedSelfPlay
+    from go_ai.policies.baselines import greedy_val_func
+    from oracle.gogame import GoGame as OG
+    states = random_positions(7, 6, seed=9, canonical=True, pass_prob=0.1).astype(np.float64)
+    bq, bkids = search.batchqs_from_valfunc(states, greedy_val_func)
+    assert bq.shape == (6, 50)
+    for st, q, kids in zip(states, bq, bkids):
+        valid = OG.valid_moves(st)
+        want_kids = OG.children(st, canonical=True, padded=False)
+        assert len(kids) == int(valid.sum()) == len(want_kids)
+        assert all(np.array_equal(k, w) for k, w in zip(kids, want_kids))
+        want_q = np.zeros(50)
+        want_q[np.where(valid)] = [-((b - w) / 49 if not OG.game_ended(c) else 100 * np.sign(b - w))
+                                   for c in want_kids for b, w in [OG.areas(c)]]
+        assert np.array_equal(q, want_q)
+        q1, kids1 = search.qs_from_valfunc(st, greedy_val_func, None)      # group_map by position, as the reference
+        assert np.array_equal(q1, q) and len(kids1) == len(kids)
+        assert np.array_equal(search.batch_greedy_pi(q[None], valid[None])[0], search.greedy_pi(q, valid))
+    valids = np.stack([OG.valid_moves(s) for s in states])
+    pi = search.batch_temperate_pi(bq, 0.5, valids)
+    assert np.allclose(pi.sum(axis=1), 1) and np.array_equal(search.batch_temperate_pi(bq, 0, valids),
+                                                             search.batch_greedy_pi(bq, valids))
+    # symmetries: 8 images of the same stones
+    syms = GoGame.get_symmetries(states[1])
+    assert len(syms) == 8 and all(s.shape == states[1].shape and s.sum() == states[1].sum() for s in syms)
+    assert np.array_equal(syms[0], states[1]) and np.array_equal(syms[3], states[1][:, ::-1, ::-1])
+    assert data.batch_random_symmetries(states).shape == states.shape
+    sa = data.batch_combine_state_actions(states, [0, 10, 49, 48, 7, 49])
+    assert sa.shape == (6, 7, 7, 7) and sa[1, 6, 1, 3] == 1 and sa[2, 6].sum() == 0 and sa[:, 6].sum() == 4
+    # replay -> events -> numpy columns
+    sp = BatchedSelfPlay(5, 6, 2, seed=3)
+    sp.record()
+    sp.play(4)
+    replay = sp.trajectories()
+    events = data.replay_to_events(replay)
+    assert len(events) == sum(len(t) for t in replay)
+    cols = data.events_to_numpy(events)
+    assert cols[0].shape == (len(events), 6, 5, 5) and cols[0].dtype == np.float32
+    assert cols[3].shape == (len(events), 26, 6, 5, 5) and cols[4].dtype == np.uint8 and cols[6].shape == (len(events), 26)
+    assert data.events_to_numpy([]) == ([], [], [], [], [], [])
