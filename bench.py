@@ -166,9 +166,18 @@ def main():
         conv_rows = n_games // len(sp.groups) * SIZE * SIZE
     else:   # data-dependent batch sizes: rows = states sent through the net during the profiled move
         conv_rows = (sp.counters()["forwards"] - fwd0) * SIZE * SIZE / max(1, conv_n // (2 * LAYERS))
-    conv_flop = 2.0 * conv_rows * 128 * (9 * 128)
-    achieved = conv_flop / (conv_ms / conv_n * 1e-3) / 1e12          # algorithmic flops
+    conv_flop = 2.0 * conv_rows * 128 * (9 * 128)                    # algorithmic: the convolution's own multiply-adds
+    achieved = conv_flop / (conv_ms / conv_n * 1e-3) / 1e12
     peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS / 3.0
+    algo = sp.ctx.nn_conv_algo()
+    kname = {0: "k_conv3x3", 1: "k_conv3x3_wino", 2: "k_conv3x3_bf16"}[algo] + f"<{SIZE}>"
+    executed_flop = conv_flop
+    if algo == 1:
+        # Winograd F(2x2,3x3): 16 products per 2x2 output tile and (cin, cout) instead of 36, on
+        # workgroups of 112 tile rows holding NBW whole boards (conv_wino_kernels.hip)
+        t2 = ((SIZE + 1) // 2) ** 2
+        wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // (112 // t2))
+        executed_flop = 2.0 * wgs * 112 * 16 * 128 * 128
 
     # the one collective of the run: gather per-rank results (utils.py:201-204's allreduces)
     from go_ai.sharding import gather_stats, reduce_stats
@@ -181,8 +190,8 @@ def main():
     if rank == 0:
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "conv3x3_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        if os.path.exists(tpath) and args.config == "c2":          # PMC passes of THIS workload, per kernel
+            traffic = json.load(open(tpath)).get("per_kernel", {}).get(kname.split("<")[0], {}).get("hbm_bytes_per_launch")
         out = {
             "metric": f"MCTS leaf evals/sec ({SIZE}x{SIZE}, transition + NN forward)",
             "value": round(total_evals / t_max, 1),
@@ -196,11 +205,15 @@ def main():
                        "board": SIZE, "mcts": SIMS, "games_per_gpu": n_games, "parallelism": f"games sharded x{world}",
                        "stream_groups_per_gpu": len(sp.groups),
                        "weights": "random init, seed 0", "leaf_evals_timed": int(total_evals)},
-            "roofline": {"bound": "mfma", "kernel": f"k_conv3x3{'_bf16' if args.dtype == 'bf16x3' else ''}<{SIZE}>",
+            "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic if args.dtype == "f32" else None,
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
                          "avg_launch_us": round(conv_ms / conv_n * 1e3, 2), "launches_timed": conv_n,
-                         "flop_per_launch": conv_flop},
+                         "flop_per_launch": conv_flop,
+                         "algorithm": {0: "direct implicit GEMM, fp32 MFMA", 1: "Winograd F(2x2,3x3), fp32 MFMA",
+                                       2: "direct implicit GEMM, bf16 MFMA on hi+lo split operands"}[algo],
+                         "executed_mfma_flop_per_launch": executed_flop,
+                         "mfma_pipe_frac": round(executed_flop / (conv_ms / conv_n * 1e-3) / 1e12 / peak, 4)},
             "games": {"total": int(tot["games"]), "finished": int(tot["finished"]),
                       "black_wins": int(tot["black_wins"]), "white_wins": int(tot["white_wins"]),
                       "moves_played": int(tot["total_steps"])},

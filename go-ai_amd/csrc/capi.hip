@@ -117,6 +117,14 @@ int goai_load_weights(goai_ctx* ctx, const char* const* names, const float* cons
     return nn_load_weights(ctx, names, tensors_host, numels, n_tensors);
 }
 
+int goai_nn_conv_algo(goai_ctx* ctx)
+{
+    GOAI_REQUIRE(ctx, "ctx is NULL");
+    GOAI_REQUIRE(ctx->net.kind >= 0, "call goai_nn_init first");
+    if (ctx->net.dtype == GOAI_DTYPE_BF16X3) return GOAI_CONV_BF16X3;
+    return ctx->net.wino_mode ? GOAI_CONV_WINOGRAD : GOAI_CONV_DIRECT;
+}
+
 int goai_nn_forward(goai_ctx* ctx, const uint8_t* states, float* pi_logits, float* val_logits, int n, int mode)
 {
     CTX_ENTER(ctx);

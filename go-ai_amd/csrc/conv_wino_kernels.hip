@@ -1,6 +1,6 @@
 // conv_wino_kernels.hip -- the trunk's conv3x3 128 -> 128 (+ folded BatchNorm bias, optional
 // residual, ReLU; /root/reference/go_ai/models/__init__.py:234-251) in fp32 by Winograd's
-// minimal filtering F(2x2, 3x3) on the fp32 matrix cores, for boards up to 9x9.
+// minimal filtering F(2x2, 3x3) on the fp32 matrix cores.
 //
 //   Y = At [ (G g Gt) . (Bt d B) ] A      (Lavin & Gray 2016; "." = elementwise, summed over cin)
 //
@@ -10,30 +10,26 @@
 // transforms only add and subtract, G g Gt is folded into the weights on the host in fp64.
 // Results differ from the direct kernel by ordinary fp32 re-association (~1e-6).
 //
-// STATUS (round 1): correct (tests/test_gpu_nn.py passes with GOAI_CONV_ALGO=wino) but NOT faster
-// than the direct kernel yet: 208 us against 206 us per launch at 1024 boards of 9x9.  400
-// workgroups on 256 CUs run as two rounds, and a stage (32 MFMAs per wave, then an fp32 VALU
-// output transform that waits for them) is too short to hide its barrier and LDS latencies;
-// without barriers, weight staging and input transform the loop alone takes 167 us.  Opt-in
-// through GOAI_CONV_ALGO=wino; the direct kernel stays the default.
-//
-// Work decomposition.  wtiles are numbered flat, w = board * T*T + ty * T + tx (T = ceil(S/2)).
-// A workgroup (8 waves, one per CU) owns WT = 64 consecutive wtiles x all 128 output channels;
-// wave (wr, wc) owns 2 MFMA row tiles (32 wtiles) x 32 output channels.  For every position
-// xi = (p, q) of the 4x4 transform domain there is an independent GEMM
+// Work decomposition.  A workgroup (8 waves, one per CU) owns NBW whole boards = NBW * T*T
+// wtiles (T = ceil(S/2)), at most ROWS = 112 = 7 MFMA row tiles, and all 128 output channels:
+// 9x9 -> 4 boards (100 wtiles), 13x13 -> 2 (98), 19x19 -> 1 (100), 7x7 -> 7 (112), 5x5 -> 12 (108);
+// 1024 boards of 9x9 are exactly one workgroup per CU.  Wave w owns the 16 output channels
+// 16w..16w+15 for all 7 row tiles.  For every position xi = (p, q) of the 4x4 transform domain
+// there is an independent GEMM
 //   M_xi[wtile][cout] = sum_cin V_xi[wtile][cin] * U_xi[cin][cout]
 // and the four outputs of a wtile are signed sums of the M_xi, so a wave keeps FIVE accumulator
-// sets: the four outputs and a temporary for the M_xi in flight.
+// sets: the four outputs and a temporary for the M_xi in flight (140 registers).
 //
-// LDS (one workgroup per CU):
-//   IMG  the zero-padded input boards the workgroup's wtiles touch, one 32-channel chunk:
-//        [NB boards][(2T+2)^2 cells][32 ch] fp32; only real cells are ever rewritten, so the
-//        zero border written once at start is the convolution's padding;
-//   V    Bt d B for ONE row p of the transform domain: [4 q][WT wtiles][32 ch], computed once per
-//        workgroup by all threads (not per wave) from IMG -- the MFMA stages then read their A
-//        fragments with plain conflict-free ds_read_b128, exactly like the direct kernel;
-//   B    U_xi^T for the stage, [128 out][32 in] = 16 KiB, double-buffered through registers.
-// Loop: 4 channel chunks x 4 rows p x 4 columns q = 64 stages of 32 MFMAs per wave.
+// LDS:
+//   IMG  the workgroup's boards, one 32-channel chunk, compact: [NBW * P cells][32 ch] fp32 plus
+//        one all-zero cell that every off-board tap of the input transform is redirected to;
+//   V    Bt d B for ONE row p of the transform domain: [4 q][ROWS wtiles][32 ch], double-buffered:
+//        row p + 1 is transformed (by all threads, once per workgroup) while row p is multiplied,
+//        so there is one barrier per row of 4 stages (224 MFMAs per wave), not one per stage.
+// The weights U_xi never touch LDS: a wave's 16 output channels x 32 inputs of a stage are 2 KB
+// that no other wave of the workgroup needs, so each lane loads its two B fragments straight
+// from global memory (L2-resident: 1 MB per convolution), one stage ahead.
+// Loop: 4 channel chunks x 4 rows p x 4 columns q = 64 stages of 56 MFMAs per wave.
 #include "go_board.h"
 #include "goai_internal.h"
 #include "nn.h"
@@ -44,50 +40,71 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int S>
 struct Wino {
-    static constexpr int T = (S + 1) / 2, T2 = T * T, PG = 2 * T + 2, CELLS = PG * PG;
-    static constexpr int RT = 2, WT = 2 * RT * 16;                 // wtiles per workgroup
-    static constexpr int NB = (WT - 1 + T2 - 1) / T2 + 1;          // boards a workgroup can touch
-    static constexpr int IMG_U4 = NB * CELLS * 8;                  // in 16-byte units
-    static constexpr int V_U4 = 4 * WT * 8;
-    static constexpr int B_U4 = 128 * 8;
-    static constexpr int NI = (NB * S * S * 8 + 511) / 512;        // staged 16-byte pieces per thread per chunk
-    static constexpr int LDS_BYTES = (IMG_U4 + V_U4 + 2 * B_U4) * 16;
+    static constexpr int T = (S + 1) / 2, T2 = T * T, P = S * S;
+    static constexpr int MT = 7, ROWS = MT * 16;                   // wtile rows per workgroup
+    static constexpr int NBW = ROWS / T2;                          // whole boards per workgroup
+    static constexpr int WT = NBW * T2;                            // real wtiles per workgroup
+    static constexpr int VP = (WT + 7) & ~7;                       // row pitch of V per q
+    static constexpr int IMG_U4 = NBW * P * 8 + 8;                 // in 16-byte units (+ the zero cell)
+    static constexpr int ZERO_U4 = NBW * P * 8;
+    static constexpr int V_U4 = 4 * VP * 8;                        // one buffer
+    static constexpr int SLACK_U4 = (ROWS - VP) * 8;               // rows WT..ROWS-1 of the last q read past it
+    static constexpr int TAB_U4 = WT * 2;                          // 16 x u16 LDS addresses per wtile
+    static constexpr int NI = (NBW * P * 8 + 511) / 512;           // staged 16-byte pieces per thread per chunk
+    static constexpr int LDS_U4 = IMG_U4 + 2 * V_U4 + SLACK_U4 + TAB_U4;
+    static_assert(NBW >= 1, "board too large for one workgroup");
+    static_assert(LDS_U4 * 16 <= 160 * 1024, "LDS budget");
+    static_assert(IMG_U4 * 16 < 65536, "input-transform addresses are 16-bit");
 };
+
+#ifdef GOAI_CONV_STAMPS
+__device__ unsigned long long g_wino_stamps[8 * 4096];   // diagnostic build only (tools/wino_stamps.py)
+extern "C" int goai_debug_wino_stamps(unsigned long long* host_out, int n)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#define W_STAMP(i) if (threadIdx.x == 0) g_wino_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define W_STAMP(i)
+#endif
 
 __device__ __forceinline__ int wswz(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
 
 template <int S, bool RESID>
-__global__ __launch_bounds__(512, 2) void k_conv3x3_wino(const float* __restrict__ in, const float* __restrict__ wt,
-                                                         const float* __restrict__ bias,
-                                                         const float* __restrict__ resid, float* __restrict__ out,
-                                                         int nboards)
+__global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ in, const float* __restrict__ wt,
+                                                      const float* __restrict__ bias,
+                                                      const float* __restrict__ resid, float* __restrict__ out,
+                                                      int nboards)
 {
     using W = Wino<S>;
-    constexpr int P = S * S, RT = W::RT, WT = W::WT, PG = W::PG;
-    __shared__ f32x4 lds[W::IMG_U4 + W::V_U4 + 2 * W::B_U4];
+    constexpr int P = W::P, MT = W::MT;
+    __shared__ f32x4 lds[W::LDS_U4];
     f32x4* Img = lds;
     f32x4* Vs = lds + W::IMG_U4;
-    f32x4* Bs = Vs + W::V_U4;
+    uint16_t* Tab = reinterpret_cast<uint16_t*>(lds + W::IMG_U4 + 2 * W::V_U4 + W::SLACK_U4);
 
+    W_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
     const int li = lane & 15, lq = lane >> 4;
-    const long w0 = (long)blockIdx.x * WT;
-    const long total_w = (long)nboards * W::T2;
-    const int b_first = (int)(w0 / W::T2);
+    const int b_first = blockIdx.x * W::NBW;
 
-    for (int i = tid; i < W::IMG_U4; i += 512) Img[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-
-    // this thread's job in the input transform: wtile tw, 16-byte channel slot ts
-    const int tw = tid >> 3, ts = tid & 7;
-    int tbase;                                       // Img index (16-byte units) of d[0][0], slot ts
-    {
-        long w = w0 + tw;
-        if (w >= total_w) w = w0;                    // past the last board: any finite data, never stored
-        const int bl = (int)(w / W::T2) - b_first, rem = (int)(w % W::T2);
+    // V rows WT..ROWS-1 of the MFMA row tiles are padding: whatever finite values they hold only
+    // reach accumulator rows that are never stored (for q < 3 they alias the next q's first rows)
+    for (int i = tid; i < 2 * W::V_U4 + W::SLACK_U4; i += 512) Vs[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    if (tid < 8) Img[W::ZERO_U4 + tid] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    // Tab[tw][a][b] = byte address in Img (slot 0, before the slot swizzle) of cell (2ty - 1 + a,
+    // 2tx - 1 + b) of wtile tw's 4x4 input patch, or of the zero cell when that is off the board
+    for (int e = tid; e < W::WT * 16; e += 512) {
+        const int tw = e >> 4, a = (e >> 2) & 3, b = e & 3;
+        const int bl = tw / W::T2, rem = tw - bl * W::T2;
         const int ty = rem / W::T, tx = rem - ty * W::T;
-        tbase = ((bl * W::CELLS + 2 * ty * PG + 2 * tx) << 3) + ts;
+        const int y = 2 * ty - 1 + a, x = 2 * tx - 1 + b;
+        const bool ok = y >= 0 && y < S && x >= 0 && x < S;
+        Tab[e] = (uint16_t)((ok ? (bl * P + y * S + x) * 8 : W::ZERO_U4) * 16);
     }
+
+    // input-transform jobs of this thread: items (wtile tw, 16-byte channel slot ts), two passes
+    const int ts = tid & 7;
 
     f32x4 ireg[W::NI];
     auto load_img = [&](int chunk) {
@@ -95,11 +112,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino(const float* __restrict
         for (int i = 0; i < W::NI; i++) {
             const int idx = tid + i * 512;
             const int cr = idx >> 3, slot = idx & 7;
-            const int bl = cr / P, cell = cr - bl * P;
-            const int board = b_first + bl;
+            const int board = b_first + cr / P;
             f32x4 v = { 0.0f, 0.0f, 0.0f, 0.0f };
-            if (idx < W::NB * P * 8 && board < nboards)
-                v = *reinterpret_cast<const f32x4*>(&in[((long)board * P + cell) * 128 + chunk * 32 + slot * 4]);
+            if (idx < W::NBW * P * 8 && board < nboards)
+                v = *reinterpret_cast<const f32x4*>(&in[((long)b_first * P + cr) * 128 + chunk * 32 + slot * 4]);
             ireg[i] = v;
         }
     };
@@ -107,102 +123,112 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino(const float* __restrict
 #pragma unroll
         for (int i = 0; i < W::NI; i++) {
             const int idx = tid + i * 512;
-            const int cr = idx >> 3, slot = idx & 7;
-            const int bl = cr / P, cell = cr - bl * P;
-            const int y = cell / S, x = cell - y * S;
-            if (idx < W::NB * P * 8) Img[((bl * W::CELLS + (y + 1) * PG + (x + 1)) << 3) + slot] = ireg[i];
-        }
-    };
-    f32x4 breg[2];
-    auto load_b = [&](int stage) {
-        const float* src = wt + (size_t)stage * 128 * 32;
-#pragma unroll
-        for (int i = 0; i < 2; i++) breg[i] = *reinterpret_cast<const f32x4*>(&src[(tid + i * 512) * 4]);
-    };
-    auto store_b = [&](int buf) {
-        f32x4* dst = Bs + buf * W::B_U4;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int idx = tid + i * 512;
-            dst[wswz(idx >> 3, idx & 7)] = breg[i];
+            if (idx < W::NBW * P * 8) Img[wswz(idx >> 3, idx & 7)] = ireg[i];
         }
     };
     // V[q][tw][ts] = (Bt d B)[p][q] for q = 0..3: rows of Bt are (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
-    auto transform = [&](int p) {
+    auto img_at = [&](uint32_t byte_addr) -> f32x4 {
+        // slot swizzle of wswz() on a byte address: cell = addr >> 7, zero cell: every slot is zero
+        const uint32_t cell = byte_addr >> 7;
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Img) + byte_addr +
+                                               ((ts ^ ((cell >> 1) & 7)) << 4));
+    };
+    auto transform = [&](int p, int vbuf) {
         const int a1 = (p == 0) ? 0 : 1, a2 = (p == 3) ? 3 : 2;
         const float s1 = (p == 2) ? -1.0f : 1.0f, s2 = (p == 0 || p == 3) ? -1.0f : 1.0f;
-        f32x4 r[4];
+        f32x4* V = Vs + vbuf * W::V_U4;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const f32x4 d1 = Img[tbase + ((a1 * PG + b) << 3)], d2 = Img[tbase + ((a2 * PG + b) << 3)];
-            r[b] = s1 * d1 + s2 * d2;
+        for (int j = 0; j < 2; j++) {
+            const int tw = (tid >> 3) + 64 * j;
+            if (tw >= W::WT) continue;
+            const uint2 t1 = *reinterpret_cast<const uint2*>(&Tab[tw * 16 + a1 * 4]);
+            const uint2 t2 = *reinterpret_cast<const uint2*>(&Tab[tw * 16 + a2 * 4]);
+            f32x4 r[4];
+            r[0] = s1 * img_at(t1.x & 0xffffu) + s2 * img_at(t2.x & 0xffffu);
+            r[1] = s1 * img_at(t1.x >> 16) + s2 * img_at(t2.x >> 16);
+            r[2] = s1 * img_at(t1.y & 0xffffu) + s2 * img_at(t2.y & 0xffffu);
+            r[3] = s1 * img_at(t1.y >> 16) + s2 * img_at(t2.y >> 16);
+            V[wswz(0 * W::VP + tw, ts)] = r[0] - r[2];
+            V[wswz(1 * W::VP + tw, ts)] = r[1] + r[2];
+            V[wswz(2 * W::VP + tw, ts)] = r[2] - r[1];
+            V[wswz(3 * W::VP + tw, ts)] = r[1] - r[3];
         }
-        Vs[wswz(0 * WT + tw, ts)] = r[0] - r[2];
-        Vs[wswz(1 * WT + tw, ts)] = r[1] + r[2];
-        Vs[wswz(2 * WT + tw, ts)] = r[2] - r[1];
-        Vs[wswz(3 * WT + tw, ts)] = r[1] - r[3];
     };
 
-    int brow[2];
-#pragma unroll
-    for (int tn = 0; tn < 2; tn++) brow[tn] = wc * 32 + tn * 16 + li;
+    // weight fragments of a stage: U[stage][cout = 16 wave + li][32 in], k = kk*16 + lq*4 + jj
+    const float* wsrc = wt + (size_t)(wave * 16 + li) * 32 + lq * 4;
+    f32x4 bcur[2], bnxt[2];
+    auto load_b = [&](int stage, f32x4* b) {
+        const float* src = wsrc + (size_t)stage * 128 * 32;
+        b[0] = *reinterpret_cast<const f32x4*>(src);
+        b[1] = *reinterpret_cast<const f32x4*>(src + 16);
+    };
 
-    f32x4 Y[2][2][RT][2];                            // [i][j]: output (2ty + i, 2tx + j) of the wtile
+    f32x4 Y[2][2][MT];                               // [i][j]: output (2ty + i, 2tx + j) of the wtile
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int t = 0; t < RT; t++)
-#pragma unroll
-                for (int tn = 0; tn < 2; tn++) Y[i][j][t][tn] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+            for (int t = 0; t < MT; t++) Y[i][j][t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 
     load_img(0);
-    load_b(0);
-    __syncthreads();                                 // the zero fill is complete
+    load_b(0, bcur);
+    __syncthreads();                                 // the zero fills are complete
     store_img();
-    store_b(0);
+    __syncthreads();
+    transform(0, 0);
     __syncthreads();
 
+    W_STAMP(1);
+#ifdef ABL_PRIO
+    if (wave < 4) __builtin_amdgcn_s_setprio(2);
+#endif
+#pragma unroll 1
     for (int chunk = 0; chunk < 4; chunk++) {
+        if (chunk == 1) { W_STAMP(2); }
+        if (chunk == 3) { W_STAMP(3); }
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            transform(p);                            // the previous stage's barrier freed V
-            __syncthreads();
+            // The NEXT row is transformed into the other V buffer while this one is multiplied.  The two
+            // waves that share a SIMD (w and w + 4) do it in different stages of the row, so that the
+            // matrix pipe always has the other wave's MFMAs to run meanwhile.
+            const bool more = p < 3 || chunk + 1 < 4;
+            if (p == 2 && chunk + 1 < 4) load_img(chunk + 1);
+            if (p == 3 && chunk + 1 < 4) {
+                store_img();                         // every transform of this chunk ended before the last barrier
+                __syncthreads();
+            }
+            const int tq = (wave < 4) ? 0 : 2;
+            const f32x4* V = Vs + (p & 1) * W::V_U4;
 #pragma unroll 1
             for (int q = 0; q < 4; q++) {
+#ifndef ABL_NOTRANS
+                if (more && q == tq) transform((p + 1) & 3, (p + 1) & 1);
+#endif
                 const int s = chunk * 16 + p * 4 + q;
-                const int buf = s & 1;
-                if (s + 1 < 64) load_b(s + 1);
-                const bool last_of_chunk = (p == 3 && q == 3);
-                if (last_of_chunk && chunk + 1 < 4) load_img(chunk + 1);
+#ifndef ABL_NOB
+                if (s + 1 < 64) load_b(s + 1, bnxt);
+#endif
 
-                const f32x4* Bb = Bs + buf * W::B_U4;
-                f32x4 b[2][2], a[RT][2];
+                f32x4 m[MT];
 #pragma unroll
-                for (int kk = 0; kk < 2; kk++)
+                for (int t = 0; t < MT; t++) m[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
-                    for (int tn = 0; tn < 2; tn++) b[kk][tn] = Bb[wswz(brow[tn], kk * 4 + lq)];
+                for (int kk = 0; kk < 2; kk++) {
+                    f32x4 a[MT];
 #pragma unroll
-                for (int t = 0; t < RT; t++)
-#pragma unroll
-                    for (int kk = 0; kk < 2; kk++) a[t][kk] = Vs[wswz(q * WT + (wr * RT + t) * 16 + li, kk * 4 + lq)];
-
-                f32x4 m[RT][2];
-#pragma unroll
-                for (int t = 0; t < RT; t++)
-#pragma unroll
-                    for (int tn = 0; tn < 2; tn++) m[t][tn] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-#pragma unroll
-                for (int kk = 0; kk < 2; kk++)
+#ifdef ABL_NOA
+                    for (int t = 0; t < MT; t++) a[t] = (t == 0) ? V[wswz(q * W::VP + t * 16 + li, kk * 4 + lq)] : f32x4{ 1.0f, 2.0f, 3.0f, (float)q };
+#else
+                    for (int t = 0; t < MT; t++) a[t] = V[wswz(q * W::VP + t * 16 + li, kk * 4 + lq)];
+#endif
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++)
 #pragma unroll
-                        for (int t = 0; t < RT; t++)
-#pragma unroll
-                            for (int tn = 0; tn < 2; tn++)
-                                m[t][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][kk][jj], b[kk][tn][jj], m[t][tn], 0, 0, 0);
-
+                        for (int t = 0; t < MT; t++)
+                            m[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[kk][jj], a[t][jj], m[t], 0, 0, 0);
+                }
                 // output transform: Y[i][j] += At[i][p] * At[j][q] * M,  At = (1 1 1 0 ; 0 1 -1 -1);
                 // p is unrolled (compile-time row factor), q is a run-time loop (column factor as +-1.0 / 0)
                 const float cj0 = (q < 3) ? 1.0f : 0.0f;
@@ -210,74 +236,92 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino(const float* __restrict
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
                     const int ci = (i == 0) ? (p < 3 ? 1 : 0) : (p == 0 ? 0 : (p == 1 ? 1 : -1));
+#ifdef ABL_NOOUT
+                    if (ci != 0 && i == 0 && p == 0) {
+#else
                     if (ci != 0) {
+#endif
                         const float f0 = ci > 0 ? cj0 : -cj0, f1 = ci > 0 ? cj1 : -cj1;
 #pragma unroll
-                        for (int t = 0; t < RT; t++)
+                        for (int t = 0; t < MT; t++)
 #pragma unroll
-                            for (int tn = 0; tn < 2; tn++)
-#pragma unroll
-                                for (int e = 0; e < 4; e++) {
-                                    Y[i][0][t][tn][e] = fmaf(f0, m[t][tn][e], Y[i][0][t][tn][e]);
-                                    Y[i][1][t][tn][e] = fmaf(f1, m[t][tn][e], Y[i][1][t][tn][e]);
-                                }
+                            for (int e = 0; e < 4; e++) {
+                                Y[i][0][t][e] = fmaf(f0, m[t][e], Y[i][0][t][e]);
+                                Y[i][1][t][e] = fmaf(f1, m[t][e], Y[i][1][t][e]);
+                            }
                     }
                 }
-
-                if (s + 1 < 64) store_b(buf ^ 1);     // buf^1 was last read in stage s-1
-                if (last_of_chunk && chunk + 1 < 4) store_img();   // the transforms of this chunk are done
-                __syncthreads();
+#ifndef ABL_NOB
+                bcur[0] = bnxt[0];
+                bcur[1] = bnxt[1];
+#endif
             }
+            __syncthreads();
         }
     }
 
-    // epilogue.  C/D layout of a 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + reg.
+    W_STAMP(4);
+    // epilogue.  The products are formed transposed (A operand = weights, B operand = V), so in the
+    // C/D layout of a 16x16 tile (col = lane & 15, row = 4 * (lane >> 4) + reg) a lane holds FOUR
+    // CONSECUTIVE output channels of ONE wtile: one 16-byte load / store per output cell.
+    const int col = wave * 16 + 4 * lq;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col]);
 #pragma unroll
-    for (int t = 0; t < RT; t++)
+    for (int t = 0; t < MT; t++) {
+        const int w = t * 16 + li;
+        const int bl = w / W::T2, rem = w - bl * W::T2;
+        const long board = b_first + bl;
+        if (w >= W::WT || board >= nboards) continue;
+        const int ty = rem / W::T, tx = rem - ty * W::T;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const long w = w0 + (wr * RT + t) * 16 + 4 * lq + r;
-            if (w >= total_w) continue;
-            const long board = w / W::T2;
-            const int rem = (int)(w - board * W::T2);
-            const int ty = rem / W::T, tx = rem - ty * W::T;
+        for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 2; j++) {
+                const int y = 2 * ty + i, x = 2 * tx + j;
+#ifdef ABL_NOEPI
+                if (y < S && x < S && bv[0] == 123.456f) {
+#else
+                if (y < S && x < S) {
+#endif
+                    const long off = (board * P + y * S + x) * 128 + col;
+                    f32x4 v = Y[i][j][t] + bv;
+                    if (RESID) v += *reinterpret_cast<const f32x4*>(&resid[off]);
 #pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const int y = 2 * ty + i, x = 2 * tx + j;
-                    if (y < S && x < S) {
-                        const long rowoff = (board * P + y * S + x) * 128;
-#pragma unroll
-                        for (int tn = 0; tn < 2; tn++) {
-                            const int col = wc * 32 + tn * 16 + li;
-                            float v = Y[i][j][t][tn][r] + bias[col];
-                            if (RESID) v += resid[rowoff + col];
-                            out[rowoff + col] = fmaxf(v, 0.0f);
-                        }
-                    }
+                    for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
+                    *reinterpret_cast<f32x4*>(&out[off]) = v;
                 }
-        }
+            }
+    }
+    W_STAMP(5);
+}
+
+template <int S>
+static int launch_wino_size(const float* in, const float* wt_wino, const float* bias, const float* resid, float* out,
+                            int nboards, hipStream_t st)
+{
+    const int grid = (nboards + Wino<S>::NBW - 1) / Wino<S>::NBW;
+    if (resid) k_conv3x3_wino<S, true><<<dim3(grid), dim3(512), 0, st>>>(in, wt_wino, bias, resid, out, nboards);
+    else k_conv3x3_wino<S, false><<<dim3(grid), dim3(512), 0, st>>>(in, wt_wino, bias, resid, out, nboards);
+    GOAI_HIP_CHECK(hipGetLastError());
+    return GOAI_OK;
+}
+
+int wino_boards_per_wg(int S_rt)
+{
+    switch (S_rt) {
+        case 5: return Wino<5>::NBW;
+        case 7: return Wino<7>::NBW;
+        case 9: return Wino<9>::NBW;
+        case 13: return Wino<13>::NBW;
+        case 19: return Wino<19>::NBW;
+        default: return 1;
+    }
 }
 
 int launch_conv3x3_wino(int S_rt, const float* in, const float* wt_wino, const float* bias, const float* resid,
                         float* out, int nboards, hipStream_t st)
 {
-#define GOAI_WINO_CASE(SZ)                                                                                     \
-    case SZ: {                                                                                                 \
-        const long total = (long)nboards * Wino<SZ>::T2;                                                       \
-        const int grid = (int)((total + Wino<SZ>::WT - 1) / Wino<SZ>::WT);                                     \
-        if (resid) k_conv3x3_wino<SZ, true><<<dim3(grid), dim3(512), 0, st>>>(in, wt_wino, bias, resid, out, nboards); \
-        else k_conv3x3_wino<SZ, false><<<dim3(grid), dim3(512), 0, st>>>(in, wt_wino, bias, resid, out, nboards);     \
-    } break
-    switch (S_rt) {
-        GOAI_WINO_CASE(5);
-        GOAI_WINO_CASE(7);
-        GOAI_WINO_CASE(9);
-        default: set_error("the Winograd convolution supports boards up to 9x9"); return GOAI_ERR_ARG;
-    }
-#undef GOAI_WINO_CASE
-    GOAI_HIP_CHECK(hipGetLastError());
+    GOAI_DISPATCH_SIZE(S_rt, return launch_wino_size<S>(in, wt_wino, bias, resid, out, nboards, st));
     return GOAI_OK;
 }
 

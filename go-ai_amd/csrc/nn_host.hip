@@ -53,10 +53,29 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
     if ((rc = dev_alloc(c, (void**)&n.w0, 54 * 128 * sizeof(float)))) return rc;
     if ((rc = dev_alloc(c, (void**)&n.b0, 128 * sizeof(float)))) return rc;
     if (layers > 0) {
-        // fp32: Winograd F(2x2,3x3) for boards up to 9x9 (conv_wino_kernels.hip) unless GOAI_CONV_ALGO=direct
+        // fp32 trunk: Winograd F(2x2,3x3) (conv_wino_kernels.hip) or the direct implicit GEMM
+        // (conv_kernels.hip).  Winograd does 1.8-2x less matrix work from 9x9 up but runs as whole
+        // workgroups of ~100 output tiles, one per CU, so it only pays when those fill the chip.
+        // The choice is made HERE, once, from max_batch, not per launch: a position's
+        // network output must not depend on how many other positions share its batch (the two
+        // kernels round differently).  GOAI_CONV_ALGO=direct / wino forces one of them.
         const char* algo = getenv("GOAI_CONV_ALGO");
-        n.use_wino = dtype == GOAI_DTYPE_F32 && c->S <= 9 && algo && std::string(algo) == "wino";
-        if (n.use_wino && (rc = dev_alloc(c, (void**)&n.wt_wino, (size_t)2 * layers * 16 * 128 * 128 * sizeof(float))))
+        n.wino_mode = 0;
+        if (dtype == GOAI_DTYPE_F32) {
+            if (algo && std::string(algo) == "wino") n.wino_mode = 2;
+            else if (!(algo && std::string(algo) == "direct") && c->S >= 9) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                    prop.multiProcessorCount > 0)
+                    n.n_cu = prop.multiProcessorCount;
+                // one workgroup per CU and round: Winograd when the last round is at least 3/4 full
+                const int nbw = wino_boards_per_wg(c->S);
+                const int grid = (max_batch + nbw - 1) / nbw, rounds = (grid + n.n_cu - 1) / n.n_cu;
+                if (4 * grid >= 3 * rounds * n.n_cu) n.wino_mode = 2;
+            }
+        }
+        if (n.wino_mode && (rc = dev_alloc(c, (void**)&n.wt_wino, (size_t)2 * layers * 16 * 128 * 128 * sizeof(float))))
             return rc;
         if (dtype == GOAI_DTYPE_BF16X3) {
             if ((rc = dev_alloc(c, &n.wt_bf16, (size_t)2 * layers * WT_BF16_PER_CONV * sizeof(uint16_t)))) return rc;
@@ -160,7 +179,7 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
                                      wb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             continue;
         }
-        if (net.use_wino) {
+        if (net.wino_mode) {
             // U = G g Gt per (cout, cin), G = (1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1), in fp64, BN scale folded
             static const double Gm[4][3] = { { 1, 0, 0 }, { 0.5, 0.5, 0.5 }, { 0.5, -0.5, 0.5 }, { 0, 0, 1 } };
             std::vector<float> wu((size_t)16 * 128 * 128);
@@ -236,7 +255,8 @@ static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const f
     if (net.dtype == GOAI_DTYPE_BF16X3)
         return launch_conv3x3_bf16(c->S, in, (const uint16_t*)net.wt_bf16 + (size_t)l * WT_BF16_PER_CONV, b, resid, out, M,
                                    c->stream);
-    if (net.use_wino)
+    const bool wino = net.wino_mode == 2;
+    if (wino)
         return launch_conv3x3_wino(c->S, in, net.wt_wino + (size_t)l * 16 * 128 * 128, b, resid, out, M / c->P, c->stream);
     return launch_conv3x3(c->S, in, net.wt + (size_t)l * 9 * 128 * 128, b, resid, out, M, c->stream);
 }

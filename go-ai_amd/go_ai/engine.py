@@ -105,6 +105,15 @@ class Context:
         self.net_kind = int(net_kind)
         _hip.check(_hip.lib.goai_nn_init(self._h, self.net_kind, int(n_blocks), int(max_batch), int(dtype)))
 
+    CONV_DIRECT, CONV_WINOGRAD, CONV_BF16X3 = 0, 1, 2
+
+    def nn_conv_algo(self):
+        """The 3x3 convolution kernel nn_init chose for this context (CONV_*)."""
+        rc = _hip.lib.goai_nn_conv_algo(self._h)
+        if rc < 0:
+            _hip.check(rc)
+        return rc
+
     def load_weights(self, state_dict):
         """state_dict: mapping of the reference's keys to float tensors / arrays (host)."""
         names, arrays = [], []

@@ -124,12 +124,18 @@ def test_bf16x3_forward_within_fp32_tolerance(kind, size, n, layers, max_batch, 
     ("ac", 7, 50, 3, 64),
     ("ac", 5, 77, 3, 256),
     ("ac", 9, 1, 3, 8),
+    ("ac", 13, 45, 3, 64),      # 2 boards per workgroup, odd board count
+    ("val", 13, 7, 3, 8),
+    ("ac", 19, 9, 3, 16),       # 1 board per workgroup
+    ("ac", 19, 5, 10, 8),       # the deeper trunk of BASELINE.json configs[4]
 ])
 def test_winograd_forward_matches_torch_oracle(kind, size, n, layers, max_batch, monkeypatch):
     """GOAI_CONV_ALGO=wino: fp32 Winograd F(2x2,3x3) trunk (conv_wino_kernels.hip), same fp32 bound."""
+    from go_ai.engine import Context
     monkeypatch.setenv("GOAI_CONV_ALGO", "wino")
     c, sd = make_ctx(kind, size, 100 + size + layers, layers, max_batch)
     monkeypatch.delenv("GOAI_CONV_ALGO")
+    assert c.nn_conv_algo() == Context.CONV_WINOGRAD
     states = random_positions(size, n, seed=size * 7 + n, canonical=True, pass_prob=0.05)
     want_pi, want_val = nn_ref.forward(sd, torch.tensor(states), kind)
     pi, val = c.nn_forward(states, mode=c.NN_RAW)
@@ -181,4 +187,30 @@ def test_load_weights_errors():
     bad["act_head.4.weight"] = bad["act_head.4.weight"][:, :-1]
     with pytest.raises(_hip.GoaiError, match="elements"):
         c.load_weights(bad)
+    c.close()
+
+
+def test_conv_algorithm_is_fixed_per_context(monkeypatch):
+    """goai_nn_init picks the trunk kernel once, from max_batch (Winograd when its workgroups fill
+    the chip, boards >= 9x9), so a position's output does not depend on its batch."""
+    from go_ai.engine import Context
+    monkeypatch.delenv("GOAI_CONV_ALGO", raising=False)
+    for size, max_batch, want in [(9, 1024, Context.CONV_WINOGRAD), (9, 64, Context.CONV_DIRECT),
+                                  (5, 4096, Context.CONV_DIRECT), (19, 512, Context.CONV_WINOGRAD)]:
+        c = Context(size)
+        c.nn_init(Context.NET_AC, 3, max_batch)
+        assert c.nn_conv_algo() == want, (size, max_batch)
+        c.close()
+    c = Context(9)
+    c.nn_init(Context.NET_AC, 3, 256, dtype=Context.DTYPE_BF16X3)
+    assert c.nn_conv_algo() == Context.CONV_BF16X3
+    c.close()
+    c, sd = make_ctx("ac", 9, 5, 3, 1024)
+    assert c.nn_conv_algo() == Context.CONV_WINOGRAD
+    states = random_positions(9, 300, seed=3, canonical=True, pass_prob=0.05)
+    pi, val = c.nn_forward(states, mode=c.NN_RAW)
+    pi1, val1 = c.nn_forward(states[7:8], mode=c.NN_RAW)
+    assert np.array_equal(pi1.cpu().numpy()[0], pi.cpu().numpy()[7]) and np.array_equal(val1.cpu().numpy()[0], val.cpu().numpy()[7])
+    want_pi, want_val = nn_ref.forward(sd, torch.tensor(states), "ac")
+    assert rel_err(val.cpu().numpy(), want_val.numpy()) < REL_TOL and rel_err(pi.cpu().numpy(), want_pi.numpy()) < REL_TOL
     c.close()
