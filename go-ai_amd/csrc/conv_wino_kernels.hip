@@ -63,7 +63,7 @@ extern "C" int goai_debug_wino_stamps(unsigned long long* host_out, int n)
 {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino_stamps), (size_t)n * sizeof(unsigned long long));
 }
-#define W_STAMP(i) if (threadIdx.x == 0) g_wino_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
+#define W_STAMP(i) if (threadIdx.x == 0) { g_wino_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); if ((i) == 1 || (i) == 4) g_wino_stamps[blockIdx.x * 8 + 6 + ((i) == 4)] = __builtin_amdgcn_s_memtime(); }
 #else
 #define W_STAMP(i)
 #endif

@@ -22,3 +22,5 @@ pr = lambda name, x: print(f"{name}: min {x.min():.1f} p50 {np.median(x):.1f} p9
 pr(names[0], t[:, 0])
 for i in range(1, 6): pr(names[i], t[:, i] - t[:, i - 1])
 pr("end", t[:, 5])
+cyc = (a[:, 7] - a[:, 6]).astype(float); us = (a[:, 4] - a[:, 1]) / 100.0
+print(f"main loop: {np.median(cyc):.0f} shader cycles in {np.median(us):.1f} us -> in-kernel clock {np.median(cyc / us) / 1e3:.3f} GHz; {np.median(cyc) / 64:.0f} cycles per stage (MFMA pipe needs 3584)")
