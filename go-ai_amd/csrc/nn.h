@@ -24,6 +24,7 @@ struct Net {
     float shift = 0.0f;        // input shift: 0.5 for the AC net (ac_net.py:41), 0 for the value net
     float* w0 = nullptr;       // [54][128]   conv0, k = ci*9 + tap
     float* b0 = nullptr;       // [128]
+    void* w0_split = nullptr;  // conv0 on the bf16 matrix cores: [3 bf16 parts of w][3 k-steps][128 out][4 taps x 8 ch] (null: VALU kernel)
     int dtype = 0;             // GOAI_DTYPE_F32 / GOAI_DTYPE_BF16X3: arithmetic of the 3x3 trunk convolutions
     float* wt = nullptr;       // f32:  [2*layers][4 chunks][9 taps][128 out][32 in]
     float* wt_wino = nullptr;  // f32 Winograd F(2x2,3x3): [2*layers][4 chunks][16 xi][128 out][32 in] = G g Gt (null: direct only)
@@ -36,8 +37,8 @@ struct Net {
     float* act[3] = { nullptr, nullptr, nullptr };   // activation buffers [max_batch*P][128]
 };
 
-int launch_conv0(int S, const uint8_t* states, const float* w0, const float* b0, float shift, float* out,
-                 int nboards, hipStream_t st);
+int launch_conv0(int S, const uint8_t* states, const float* w0, const void* w0_split, const float* b0, float shift,
+                 float* out, int nboards, hipStream_t st);
 int launch_conv3x3(int S, const float* in, const float* wt, const float* bias, const float* resid, float* out, int M,
                    hipStream_t st);
 int launch_conv3x3_bf16(int S, const float* in, const void* wt_bf16, const float* bias, const float* resid, float* out,

@@ -52,6 +52,11 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
     int rc;
     if ((rc = dev_alloc(c, (void**)&n.w0, 54 * 128 * sizeof(float)))) return rc;
     if ((rc = dev_alloc(c, (void**)&n.b0, 128 * sizeof(float)))) return rc;
+    {
+        const char* c0 = getenv("GOAI_CONV0");            // "valu": the fp32 VALU kernel (A/B timing)
+        if (!(c0 && std::string(c0) == "valu") && (rc = dev_alloc(c, &n.w0_split, 3 * 3 * 128 * 32 * sizeof(uint16_t))))
+            return rc;
+    }
     if (layers > 0) {
         // fp32 trunk: Winograd F(2x2,3x3) (conv_wino_kernels.hip) or the direct implicit GEMM
         // (conv_kernels.hip).  Winograd does 1.8-2x less matrix work from 9x9 up but runs as whole
@@ -148,6 +153,23 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
     }
     GOAI_HIP_CHECK(hipMemcpy(net.w0, w0.data(), w0.size() * sizeof(float), hipMemcpyHostToDevice));
     GOAI_HIP_CHECK(hipMemcpy(net.b0, b0.data(), b0.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (net.w0_split) {
+        // every folded fp32 weight as the exact sum of three bf16 numbers; k = tap * 8 + channel
+        std::vector<uint16_t> ws((size_t)3 * 3 * 128 * 32, 0);
+        auto bf_to_f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+        for (int co = 0; co < 128; co++)
+            for (int ci = 0; ci < 6; ci++)
+                for (int tap = 0; tap < 9; tap++) {
+                    float r = w0[(ci * 9 + tap) * 128 + co];
+                    for (int sp = 0; sp < 3; sp++) {
+                        const uint16_t h = bf16_rne(r);
+                        ws[(((size_t)sp * 3 + tap / 4) * 128 + co) * 32 + (tap % 4) * 8 + ci] = h;
+                        r -= bf_to_f(h);
+                    }
+                    // r == 0 here unless a part fell into the bf16 denormal range (|w| < 2^-110)
+                }
+        GOAI_HIP_CHECK(hipMemcpy(net.w0_split, ws.data(), ws.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
 
     // trunk convs -> [conv][chunk][tap][cout][32 cin]
     std::vector<float> wt((size_t)9 * 128 * 128), bt(128);
@@ -285,7 +307,7 @@ int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, in
         const int nb = (n - done) < net.max_batch ? (n - done) : net.max_batch;
         const int M = nb * P;
         int rc;
-        if ((rc = launch_conv0(c->S, states + (size_t)done * 6 * P, net.w0, net.b0, net.shift, net.act[0], nb, c->stream)))
+        if ((rc = launch_conv0(c->S, states + (size_t)done * 6 * P, net.w0, net.w0_split, net.b0, net.shift, net.act[0], nb, c->stream)))
             return rc;
         float *x = net.act[0], *y = net.act[1], *z = net.act[2];
         for (int l = 0; l < net.layers; l++) {

@@ -19,6 +19,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // --------------------------------------------------------------------------------------
 // conv0: 6 -> 128, 3x3, pad 1, + folded BN + ReLU, reading the uint8 state planes.
+// fp32 VALU version (GOAI_CONV0=valu; the default is k_conv0_mfma below, 29 -> 12 us).
 // One 256-thread workgroup per board; thread = (output channel, cell parity); the 54 weights
 // of the thread's channel stay in registers, the board sits in LDS as [cell][8] floats with
 // a zero border (padding is applied AFTER the AC net's -0.5 input shift, so it is 0).
@@ -61,6 +62,93 @@ __global__ __launch_bounds__(256) void k_conv0(const uint8_t* __restrict__ state
                 acc = fmaf(hi[1], w[5 * 9 + t], acc);
             }
             out[((size_t)b * G::P + p) * 128 + cout] = fmaxf(acc, 0.0f);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// conv0 on the bf16 matrix cores, exactly: the inputs are 0 / 1 (value net) or -0.5 / +0.5
+// (actor-critic net) and 0 in the padding, all exact in bf16, and every fp32 weight is the sum
+// of three bf16 numbers (w1 = bf16(w), w2 = bf16(w - w1), w3 = bf16(w - w1 - w2): 3 x 8
+// significant bits), so x * w = x*w1 + x*w2 + x*w3 with every product exact in the fp32
+// accumulator -- the result differs from the fmaf chain of k_conv0 only by the order of the
+// fp32 additions.  K is laid out as tap * 8 + channel (6 real channels, 12 taps: 3 k-steps of
+// 32), so a lane's 8 consecutive k are ONE neighbour cell's channels = one 16-byte LDS read.
+// Products are formed transposed (A = weights, B = cells): a lane ends with 4 consecutive
+// output channels of one cell -> 16-byte stores.  Workgroup = 4 waves x 32 output channels,
+// NB0 boards; the 72 weight registers of a wave are loaded once.
+// --------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int NB0 = 2;      // boards per workgroup (measured at 1024 boards of 9x9: 4 -> 13.4 us, 2 -> 11.7 us, 1 -> 13.2 us)
+
+template <int S>
+__global__ __launch_bounds__(256) void k_conv0_mfma(const uint8_t* __restrict__ states, const uint4* __restrict__ w0s,
+                                                    const float* __restrict__ b0, float shift,
+                                                    float* __restrict__ out, int nboards)
+{
+    using G = Geom<S>;
+    constexpr int CELLS = NB0 * G::P, TILES = (CELLS + 15) / 16;
+    __shared__ uint4 xin[NB0 * G::NPAD + 1];                       // [board][padded cell] 8 bf16; last = zero cell
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int b_first = blockIdx.x * NB0;
+
+    // weights: w0s[split][kstep][cout][kgroup] = 8 bf16
+    bf16x8 wa[2][3][3];                                            // [cout tile of the wave][kstep][split]
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int ks = 0; ks < 3; ks++)
+#pragma unroll
+            for (int sp = 0; sp < 3; sp++)
+                wa[ct][ks][sp] = __builtin_bit_cast(bf16x8, w0s[((sp * 3 + ks) * 128 + wave * 32 + ct * 16 + li) * 4 + lq]);
+    f32x4 bias[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) bias[ct] = *reinterpret_cast<const f32x4*>(&b0[wave * 32 + ct * 16 + 4 * lq]);
+
+    for (int i = tid; i < NB0 * G::NPAD + 1; i += 256) xin[i] = uint4{ 0u, 0u, 0u, 0u };
+    __syncthreads();
+    // planes -> bf16 (x - shift): one thread per (board, cell), 6 channels packed into 16 bytes
+    const uint32_t one = __builtin_bit_cast(uint16_t, (__bf16)(1.0f - shift)), zer = __builtin_bit_cast(uint16_t, (__bf16)(0.0f - shift));
+    for (int i = tid; i < CELLS; i += 256) {
+        const int bl = i / G::P, p = i - bl * G::P;
+        if (b_first + bl >= nboards) break;
+        const uint8_t* st = states + ((size_t)(b_first + bl) * 6) * G::P + p;
+        uint32_t h[6];
+#pragma unroll
+        for (int ci = 0; ci < 6; ci++) h[ci] = st[ci * G::P] ? one : zer;
+        xin[bl * G::NPAD + cell_q<S>(p)] = uint4{ h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), 0u };
+    }
+    __syncthreads();
+
+    for (int t = 0; t < TILES; t++) {
+        // this lane's cell (B operand column li) and the 3 neighbour cells it feeds: tap = ks*4 + lq
+        const int cell = t * 16 + li;
+        const bool on = cell < CELLS;
+        const int bl = on ? cell / G::P : 0, p = on ? cell - bl * G::P : 0;
+        const int q = bl * G::NPAD + cell_q<S>(p);
+        f32x4 acc[2] = { bias[0], bias[1] };
+#pragma unroll
+        for (int ks = 0; ks < 3; ks++) {
+            const int tap = ks * 4 + lq;
+            const int qq = (on && tap < 9) ? q + (tap / 3 - 1) * G::PS + (tap % 3 - 1) : NB0 * G::NPAD;
+            const bf16x8 xb = __builtin_bit_cast(bf16x8, xin[qq]);
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                for (int sp = 2; sp >= 0; sp--)                    // small terms first
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ct][ks][sp], xb, acc[ct], 0, 0, 0);
+        }
+        // C/D layout: col = lane & 15 = cell, row = 4 * (lane >> 4) + reg = output channel within the tile
+        if (on && b_first + bl < nboards) {
+            float* dst = out + ((size_t)(b_first + bl) * G::P + p) * 128 + wave * 32 + 4 * lq;
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++) {
+                f32x4 v = acc[ct];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
+                *reinterpret_cast<f32x4*>(dst + ct * 16) = v;
+            }
         }
     }
 }
@@ -254,9 +342,16 @@ __global__ __launch_bounds__(64) void k_numpy_shim(const uint8_t* __restrict__ s
 }
 
 // ---- launchers ----------------------------------------------------------------------------
-int launch_conv0(int S_rt, const uint8_t* states, const float* w0, const float* b0, float shift, float* out,
-                 int nboards, hipStream_t st)
+int launch_conv0(int S_rt, const uint8_t* states, const float* w0, const void* w0_split, const float* b0, float shift,
+                 float* out, int nboards, hipStream_t st)
 {
+    if (w0_split) {
+        const int grid = (nboards + NB0 - 1) / NB0;
+        GOAI_DISPATCH_SIZE(S_rt, k_conv0_mfma<S><<<dim3(grid), dim3(256), 0, st>>>(
+                                     states, (const uint4*)w0_split, b0, shift, out, nboards));
+        GOAI_HIP_CHECK(hipGetLastError());
+        return GOAI_OK;
+    }
     int grid = nboards < 4096 ? nboards : 4096;
     GOAI_DISPATCH_SIZE(S_rt, k_conv0<S><<<dim3(grid), dim3(256), 0, st>>>(states, w0, b0, shift, out, nboards));
     GOAI_HIP_CHECK(hipGetLastError());
