@@ -170,7 +170,7 @@ def main():
     achieved = conv_flop / (conv_ms / conv_n * 1e-3) / 1e12
     peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS / 3.0
     algo = sp.ctx.nn_conv_algo()
-    kname = {0: "k_conv3x3", 1: "k_conv3x3_wino", 2: "k_conv3x3_bf16"}[algo] + f"<{SIZE}>"
+    kname = {0: "k_conv3x3", 1: "k_conv3x3_wino", 2: "k_conv3x3_bf16", 3: "k_conv3x3_wino3"}[algo] + f"<{SIZE}>"
     executed_flop = conv_flop
     if algo == 1:
         # Winograd F(2x2,3x3): 16 products per 2x2 output tile and (cin, cout) instead of 36, on
@@ -178,6 +178,10 @@ def main():
         t2 = ((SIZE + 1) // 2) ** 2
         wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // (112 // t2))
         executed_flop = 2.0 * wgs * 112 * 16 * 128 * 128
+    elif algo == 3:
+        # Winograd F(3x3,3x3): 25 products per 3x3 output tile; workgroups of 48 tile rows = 4 boards of 9x9
+        wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // 4)
+        executed_flop = 2.0 * wgs * 48 * 25 * 128 * 128
 
     # the one collective of the run: gather per-rank results (utils.py:201-204's allreduces)
     from go_ai.sharding import gather_stats, reduce_stats
@@ -211,7 +215,8 @@ def main():
                          "avg_launch_us": round(conv_ms / conv_n * 1e3, 2), "launches_timed": conv_n,
                          "flop_per_launch": conv_flop,
                          "algorithm": {0: "direct implicit GEMM, fp32 MFMA", 1: "Winograd F(2x2,3x3), fp32 MFMA",
-                                       2: "direct implicit GEMM, bf16 MFMA on hi+lo split operands"}[algo],
+                                       2: "direct implicit GEMM, bf16 MFMA on hi+lo split operands",
+                                       3: "Winograd F(3x3,3x3), fp32 MFMA"}[algo],
                          "executed_mfma_flop_per_launch": executed_flop,
                          "mfma_pipe_frac": round(executed_flop / (conv_ms / conv_n * 1e-3) / 1e12 / peak, 4)},
             "games": {"total": int(tot["games"]), "finished": int(tot["finished"]),

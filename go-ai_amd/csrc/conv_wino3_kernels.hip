@@ -1,0 +1,301 @@
+// conv_wino3_kernels.hip -- the trunk's conv3x3 128 -> 128 (+ folded BatchNorm bias, optional
+// residual, ReLU; /root/reference/go_ai/models/__init__.py:234-251) in fp32 by Winograd's
+// minimal filtering F(3x3, 3x3) on the fp32 matrix cores, for boards whose side is a multiple
+// of 3 (9x9: three tiles of three, no tile padding at all).
+//
+//   Y = At [ (G g Gt) . (Bt d B) ] A,   interpolation points 0, 1, -1, 2, inf  (Lavin & Gray 2016)
+//   At = (1 1  1 1 0)   Bt = (2 -1 -2  1 0)   G = ( 1/2    0    0 )
+//        (0 1 -1 2 0)        (0 -2 -1  1 0)       (-1/2 -1/2 -1/2 )
+//        (0 1  1 4 1)        (0  2 -3  1 0)       (-1/6  1/6 -1/6 )
+//                            (0 -1  0  1 0)       ( 1/6  1/3  2/3 )
+//                            (0  2 -1 -2 1)       (  0    0    1  )
+// A 3x3 block of outputs ("wtile") needs 25 multiplications per (cin, cout) instead of 81: 3.24x
+// fewer MFMA operations than the direct implicit GEMM, 1.78x fewer than F(2x2,3x3) on a 9x9 board
+// (whose 2x2 tiles cover 10x10).  fp32 throughout; G g Gt is folded into the weights on the host in
+// fp64.  The larger transform constants cost accuracy: ~2e-6 relative per layer (F(2x2,3x3): ~1e-6),
+// far inside the 1e-3 bound (tests/test_gpu_nn.py).
+//
+// Structure: as conv_wino_kernels.hip (whole boards per workgroup, one workgroup per CU, weights
+// L2 -> registers, double-buffered V row, table-driven input transform), with
+//   - NBW = 4 boards = 36 wtiles in MT = 3 MFMA row tiles (48 rows) per 512-thread workgroup,
+//   - 5 x 5 transform positions: 4 chunks x 5 rows p x 5 columns q = 100 stages of 24 MFMAs per wave,
+//   - nine output accumulator sets + one M in flight per wave (120 registers).
+#include "go_board.h"
+#include "goai_internal.h"
+#include "nn.h"
+
+namespace goai {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int S>
+struct Wino3 {
+    static_assert(S % 3 == 0, "F(3x3,3x3) tiles must cover the board exactly");
+    static constexpr int T = S / 3, T2 = T * T, P = S * S;
+    static constexpr int NBW = 4;                                  // whole boards per workgroup
+    static constexpr int WT = NBW * T2;                            // real wtiles per workgroup
+    static constexpr int MT = (WT + 15) / 16, ROWS = MT * 16;      // MFMA row tiles
+    static constexpr int IMG_U4 = NBW * P * 8 + 8;                 // 16-byte units (+ the zero cell)
+    static constexpr int ZERO_U4 = NBW * P * 8;
+    static constexpr int V_U4 = 5 * ROWS * 8;                      // one buffer: [5 q][ROWS][32 ch]
+    static constexpr int TAB_U4 = WT * 5;                          // [wtile][a] -> 8 x u16 (5 used)
+    static constexpr int NI = (NBW * P * 8 + 511) / 512;
+    static constexpr int LDS_U4 = IMG_U4 + 2 * V_U4 + TAB_U4;
+    static_assert(LDS_U4 * 16 <= 160 * 1024, "LDS budget");
+    static_assert(IMG_U4 * 16 < 65536, "input-transform addresses are 16-bit");
+};
+
+#ifdef GOAI_CONV_STAMPS
+__device__ unsigned long long g_wino3_stamps[8 * 4096];   // diagnostic build only (tools/wino_stamps.py)
+extern "C" int goai_debug_wino3_stamps(unsigned long long* host_out, int n)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino3_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#define W3_STAMP(i) if (threadIdx.x == 0) { g_wino3_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); if ((i) == 1 || (i) == 4) g_wino3_stamps[blockIdx.x * 8 + 6 + ((i) == 4)] = __builtin_amdgcn_s_memtime(); }
+#else
+#define W3_STAMP(i)
+#endif
+
+__device__ __forceinline__ int w3swz(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
+
+template <int S, bool RESID>
+__global__ __launch_bounds__(512) void k_conv3x3_wino3(const float* __restrict__ in, const float* __restrict__ wt,
+                                                       const float* __restrict__ bias,
+                                                       const float* __restrict__ resid, float* __restrict__ out,
+                                                       int nboards)
+{
+    using W = Wino3<S>;
+    constexpr int P = W::P, MT = W::MT, ROWS = W::ROWS;
+    __shared__ f32x4 lds[W::LDS_U4];
+    f32x4* Img = lds;
+    f32x4* Vs = lds + W::IMG_U4;
+    uint16_t* Tab = reinterpret_cast<uint16_t*>(lds + W::IMG_U4 + 2 * W::V_U4);
+
+    W3_STAMP(0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int b_first = blockIdx.x * W::NBW;
+
+    for (int i = tid; i < 2 * W::V_U4; i += 512) Vs[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };   // rows >= WT stay zero
+    if (tid < 8) Img[W::ZERO_U4 + tid] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    // Tab[tw][a][b] = byte address in Img (slot 0, before the slot swizzle) of cell (3ty - 1 + a,
+    // 3tx - 1 + b) of wtile tw's 5x5 input patch, or of the zero cell when that is off the board
+    for (int e = tid; e < W::WT * 40; e += 512) {
+        const int tw = e / 40, a = (e % 40) >> 3, b = e & 7;
+        const int bl = tw / W::T2, rem = tw - bl * W::T2;
+        const int ty = rem / W::T, tx = rem - ty * W::T;
+        const int y = 3 * ty - 1 + a, x = 3 * tx - 1 + b;
+        const bool ok = b < 5 && y >= 0 && y < S && x >= 0 && x < S;
+        Tab[e] = (uint16_t)((ok ? (bl * P + y * S + x) * 8 : W::ZERO_U4) * 16);
+    }
+
+    // input-transform job of this thread: lanes 0..8 of every 16 take one (wtile, channel slot) item
+    const int item = (tid >> 4) * 9 + (tid & 15);
+    const bool t_on = (tid & 15) < 9 && item < W::WT * 8;
+    const int ts = item & 7, ttw = t_on ? item >> 3 : 0;
+
+    f32x4 ireg[W::NI];
+    auto load_img = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < W::NI; i++) {
+            const int idx = tid + i * 512;
+            const int cr = idx >> 3, slot = idx & 7;
+            const int board = b_first + cr / P;
+            f32x4 v = { 0.0f, 0.0f, 0.0f, 0.0f };
+            if (idx < W::NBW * P * 8 && board < nboards)
+                v = *reinterpret_cast<const f32x4*>(&in[((long)b_first * P + cr) * 128 + chunk * 32 + slot * 4]);
+            ireg[i] = v;
+        }
+    };
+    auto store_img = [&]() {
+#pragma unroll
+        for (int i = 0; i < W::NI; i++) {
+            const int idx = tid + i * 512;
+            if (idx < W::NBW * P * 8) Img[w3swz(idx >> 3, idx & 7)] = ireg[i];
+        }
+    };
+    auto img_at = [&](uint32_t byte_addr) -> f32x4 {
+        const uint32_t cell = byte_addr >> 7;          // the zero cell: every slot is zero
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Img) + byte_addr +
+                                               ((ts ^ ((cell >> 1) & 7)) << 4));
+    };
+    // one row of the patch (a), the five cells b = 0..4
+    auto patch_row = [&](int a, f32x4* d) {
+        const uint4 t = *reinterpret_cast<const uint4*>(&Tab[ttw * 40 + a * 8]);
+        d[0] = img_at(t.x & 0xffffu);
+        d[1] = img_at(t.x >> 16);
+        d[2] = img_at(t.y & 0xffffu);
+        d[3] = img_at(t.y >> 16);
+        d[4] = img_at(t.z & 0xffffu);
+    };
+    // V[q][tw][ts] = (Bt d B)[p][q], q = 0..4, for row p (compile-time after unrolling)
+    auto transform = [&](int p, int vbuf) {
+        if (!t_on) return;
+        f32x4 r[5], d1[5], d2[5], d3[5];
+        patch_row(1, d1);
+        if (p != 3) patch_row(2, d2);
+        patch_row(3, d3);
+        if (p == 0) {
+            f32x4 d0[5];
+            patch_row(0, d0);
+#pragma unroll
+            for (int b = 0; b < 5; b++) r[b] = 2.0f * d0[b] - d1[b] - 2.0f * d2[b] + d3[b];
+        } else if (p == 1) {
+#pragma unroll
+            for (int b = 0; b < 5; b++) r[b] = d3[b] - 2.0f * d1[b] - d2[b];
+        } else if (p == 2) {
+#pragma unroll
+            for (int b = 0; b < 5; b++) r[b] = 2.0f * d1[b] - 3.0f * d2[b] + d3[b];
+        } else if (p == 3) {
+#pragma unroll
+            for (int b = 0; b < 5; b++) r[b] = d3[b] - d1[b];
+        } else {
+            f32x4 d4[5];
+            patch_row(4, d4);
+#pragma unroll
+            for (int b = 0; b < 5; b++) r[b] = 2.0f * d1[b] - d2[b] - 2.0f * d3[b] + d4[b];
+        }
+        f32x4* V = Vs + vbuf * W::V_U4;
+        V[w3swz(0 * ROWS + ttw, ts)] = 2.0f * r[0] - r[1] - 2.0f * r[2] + r[3];
+        V[w3swz(1 * ROWS + ttw, ts)] = r[3] - 2.0f * r[1] - r[2];
+        V[w3swz(2 * ROWS + ttw, ts)] = 2.0f * r[1] - 3.0f * r[2] + r[3];
+        V[w3swz(3 * ROWS + ttw, ts)] = r[3] - r[1];
+        V[w3swz(4 * ROWS + ttw, ts)] = 2.0f * r[1] - r[2] - 2.0f * r[3] + r[4];
+    };
+
+    // weight fragments of a stage: U[stage][cout = 16 wave + li][32 in], k = kk*16 + lq*4 + jj
+    const float* wsrc = wt + (size_t)(wave * 16 + li) * 32 + lq * 4;
+    f32x4 bcur[2], bnxt[2];
+    auto load_b = [&](int stage, f32x4* b) {
+        const float* src = wsrc + (size_t)stage * 128 * 32;
+        b[0] = *reinterpret_cast<const f32x4*>(src);
+        b[1] = *reinterpret_cast<const f32x4*>(src + 16);
+    };
+
+    f32x4 Y[3][3][MT];                               // [i][j]: output (3ty + i, 3tx + j) of the wtile
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int t = 0; t < MT; t++) Y[i][j][t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+
+    load_img(0);
+    load_b(0, bcur);
+    __syncthreads();                                 // the zero fills and the table are complete
+    store_img();
+    __syncthreads();
+    transform(0, 0);
+    __syncthreads();
+
+    const int tq = (wave < 4) ? 0 : 2;               // waves w and w + 4 share a SIMD: transform in different stages
+    W3_STAMP(1);
+#pragma unroll 1
+    for (int chunk = 0; chunk < 4; chunk++) {
+        if (chunk == 1) { W3_STAMP(2); }
+        if (chunk == 3) { W3_STAMP(3); }
+#pragma unroll
+        for (int p = 0; p < 5; p++) {
+            const int rowi = chunk * 5 + p;          // V buffer of this row = rowi & 1
+            const bool more = p < 4 || chunk + 1 < 4;
+            if (p == 3 && chunk + 1 < 4) load_img(chunk + 1);
+            if (p == 4 && chunk + 1 < 4) {
+                store_img();                         // every transform of this chunk ended before the last barrier
+                __syncthreads();
+            }
+            const f32x4* V = Vs + (rowi & 1) * W::V_U4;
+#pragma unroll 1
+            for (int q = 0; q < 5; q++) {
+                if (more && q == tq) transform(p == 4 ? 0 : p + 1, (rowi + 1) & 1);
+                const int s = rowi * 5 + q;
+                if (s + 1 < 100) load_b(s + 1, bnxt);
+
+                f32x4 m[MT];
+#pragma unroll
+                for (int t = 0; t < MT; t++) m[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++) {
+                    f32x4 a[MT];
+#pragma unroll
+                    for (int t = 0; t < MT; t++) a[t] = V[w3swz(q * ROWS + t * 16 + li, kk * 4 + lq)];
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+                        for (int t = 0; t < MT; t++)
+                            m[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[kk][jj], a[t][jj], m[t], 0, 0, 0);
+                }
+                // output transform: Y[i][j] += At[i][p] * At[j][q] * M; p is unrolled (row factors at
+                // compile time, zeros skipped), q is a run-time loop (column factors as floats)
+                const float cj0 = (q < 4) ? 1.0f : 0.0f;
+                const float cj1 = (q == 1) ? 1.0f : (q == 2 ? -1.0f : (q == 3 ? 2.0f : 0.0f));
+                const float cj2 = (q == 0) ? 0.0f : (q == 3 ? 4.0f : 1.0f);
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const int ci = (i == 0) ? (p < 4 ? 1 : 0)
+                                 : (i == 1) ? (p == 1 ? 1 : (p == 2 ? -1 : (p == 3 ? 2 : 0)))
+                                            : (p == 0 ? 0 : (p == 3 ? 4 : 1));
+                    if (ci != 0) {
+                        const float f0 = (float)ci * cj0, f1 = (float)ci * cj1, f2 = (float)ci * cj2;
+#pragma unroll
+                        for (int t = 0; t < MT; t++)
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                Y[i][0][t][e] = fmaf(f0, m[t][e], Y[i][0][t][e]);
+                                Y[i][1][t][e] = fmaf(f1, m[t][e], Y[i][1][t][e]);
+                                Y[i][2][t][e] = fmaf(f2, m[t][e], Y[i][2][t][e]);
+                            }
+                    }
+                }
+                bcur[0] = bnxt[0];
+                bcur[1] = bnxt[1];
+            }
+            __syncthreads();
+        }
+    }
+
+    W3_STAMP(4);
+    // epilogue.  The products are formed transposed (A operand = weights, B operand = V), so in the
+    // C/D layout of a 16x16 tile (col = lane & 15, row = 4 * (lane >> 4) + reg) a lane holds FOUR
+    // CONSECUTIVE output channels of ONE wtile: one 16-byte load / store per output cell.
+    const int col = wave * 16 + 4 * lq;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col]);
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        const int w = t * 16 + li;
+        const int bl = w / W::T2, rem = w - bl * W::T2;
+        const long board = b_first + bl;
+        if (w >= W::WT || board >= nboards) continue;
+        const int ty = rem / W::T, tx = rem - ty * W::T;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const long off = (board * P + (3 * ty + i) * S + 3 * tx + j) * 128 + col;
+                f32x4 v = Y[i][j][t] + bv;
+                if (RESID) v += *reinterpret_cast<const f32x4*>(&resid[off]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
+                *reinterpret_cast<f32x4*>(&out[off]) = v;
+            }
+    }
+    W3_STAMP(5);
+}
+
+int wino3_supported(int S_rt) { return S_rt == 9; }
+int wino3_boards_per_wg(int S_rt) { return S_rt == 9 ? Wino3<9>::NBW : 1; }
+
+int launch_conv3x3_wino3(int S_rt, const float* in, const float* wt_wino3, const float* bias, const float* resid,
+                         float* out, int nboards, hipStream_t st)
+{
+    if (S_rt != 9) {
+        set_error("the F(3x3,3x3) convolution is built for 9x9 boards");
+        return GOAI_ERR_ARG;
+    }
+    const int grid = (nboards + Wino3<9>::NBW - 1) / Wino3<9>::NBW;
+    if (resid) k_conv3x3_wino3<9, true><<<dim3(grid), dim3(512), 0, st>>>(in, wt_wino3, bias, resid, out, nboards);
+    else k_conv3x3_wino3<9, false><<<dim3(grid), dim3(512), 0, st>>>(in, wt_wino3, bias, resid, out, nboards);
+    GOAI_HIP_CHECK(hipGetLastError());
+    return GOAI_OK;
+}
+
+}  // namespace goai

@@ -181,9 +181,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
     __syncthreads();
 
     W_STAMP(1);
-#ifdef ABL_PRIO
-    if (wave < 4) __builtin_amdgcn_s_setprio(2);
-#endif
 #pragma unroll 1
     for (int chunk = 0; chunk < 4; chunk++) {
         if (chunk == 1) { W_STAMP(2); }
@@ -203,13 +200,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
             const f32x4* V = Vs + (p & 1) * W::V_U4;
 #pragma unroll 1
             for (int q = 0; q < 4; q++) {
-#ifndef ABL_NOTRANS
                 if (more && q == tq) transform((p + 1) & 3, (p + 1) & 1);
-#endif
                 const int s = chunk * 16 + p * 4 + q;
-#ifndef ABL_NOB
                 if (s + 1 < 64) load_b(s + 1, bnxt);
-#endif
 
                 f32x4 m[MT];
 #pragma unroll
@@ -218,11 +211,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
                 for (int kk = 0; kk < 2; kk++) {
                     f32x4 a[MT];
 #pragma unroll
-#ifdef ABL_NOA
-                    for (int t = 0; t < MT; t++) a[t] = (t == 0) ? V[wswz(q * W::VP + t * 16 + li, kk * 4 + lq)] : f32x4{ 1.0f, 2.0f, 3.0f, (float)q };
-#else
                     for (int t = 0; t < MT; t++) a[t] = V[wswz(q * W::VP + t * 16 + li, kk * 4 + lq)];
-#endif
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++)
 #pragma unroll
@@ -236,11 +225,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
                     const int ci = (i == 0) ? (p < 3 ? 1 : 0) : (p == 0 ? 0 : (p == 1 ? 1 : -1));
-#ifdef ABL_NOOUT
-                    if (ci != 0 && i == 0 && p == 0) {
-#else
                     if (ci != 0) {
-#endif
                         const float f0 = ci > 0 ? cj0 : -cj0, f1 = ci > 0 ? cj1 : -cj1;
 #pragma unroll
                         for (int t = 0; t < MT; t++)
@@ -251,10 +236,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
                             }
                     }
                 }
-#ifndef ABL_NOB
                 bcur[0] = bnxt[0];
                 bcur[1] = bnxt[1];
-#endif
             }
             __syncthreads();
         }
@@ -278,11 +261,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const int y = 2 * ty + i, x = 2 * tx + j;
-#ifdef ABL_NOEPI
-                if (y < S && x < S && bv[0] == 123.456f) {
-#else
                 if (y < S && x < S) {
-#endif
                     const long off = (board * P + y * S + x) * 128 + col;
                     f32x4 v = Y[i][j][t] + bv;
                     if (RESID) v += *reinterpret_cast<const f32x4*>(&resid[off]);

@@ -68,6 +68,7 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
         n.wino_mode = 0;
         if (dtype == GOAI_DTYPE_F32) {
             if (algo && std::string(algo) == "wino") n.wino_mode = 2;
+            else if (algo && std::string(algo) == "wino3" && wino3_supported(c->S)) n.wino_mode = 3;
             else if (!(algo && std::string(algo) == "direct") && c->S >= 9) {
                 int dev = 0;
                 hipDeviceProp_t prop;
@@ -78,9 +79,18 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
                 const int nbw = wino_boards_per_wg(c->S);
                 const int grid = (max_batch + nbw - 1) / nbw, rounds = (grid + n.n_cu - 1) / n.n_cu;
                 if (4 * grid >= 3 * rounds * n.n_cu) n.wino_mode = 2;
+                // 9x9: F(3x3,3x3) tiles the board exactly (1.8x fewer products again); same one-workgroup-
+                // per-CU shape, 4 boards each
+                if (wino3_supported(c->S)) {
+                    const int nb3 = wino3_boards_per_wg(c->S);
+                    const int g3 = (max_batch + nb3 - 1) / nb3, r3 = (g3 + n.n_cu - 1) / n.n_cu;
+                    if (4 * g3 >= 3 * r3 * n.n_cu) n.wino_mode = 3;
+                }
             }
         }
-        if (n.wino_mode && (rc = dev_alloc(c, (void**)&n.wt_wino, (size_t)2 * layers * 16 * 128 * 128 * sizeof(float))))
+        if (n.wino_mode == 2 && (rc = dev_alloc(c, (void**)&n.wt_wino, (size_t)2 * layers * 16 * 128 * 128 * sizeof(float))))
+            return rc;
+        if (n.wino_mode == 3 && (rc = dev_alloc(c, (void**)&n.wt_wino3, (size_t)2 * layers * 25 * 128 * 128 * sizeof(float))))
             return rc;
         if (dtype == GOAI_DTYPE_BF16X3) {
             if ((rc = dev_alloc(c, &n.wt_bf16, (size_t)2 * layers * WT_BF16_PER_CONV * sizeof(uint16_t)))) return rc;
@@ -201,7 +211,27 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
                                      wb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             continue;
         }
-        if (net.wino_mode) {
+        if (net.wino_mode == 3) {
+            // F(3x3,3x3): U = G g Gt (5x5) per (cout, cin) in fp64, BN scale folded
+            static const double G3[5][3] = { { 0.5, 0, 0 }, { -0.5, -0.5, -0.5 }, { -1.0 / 6, 1.0 / 6, -1.0 / 6 },
+                                             { 1.0 / 6, 1.0 / 3, 2.0 / 3 }, { 0, 0, 1 } };
+            std::vector<float> wu((size_t)25 * 128 * 128);
+            for (int co = 0; co < 128; co++)
+                for (int ci = 0; ci < 128; ci++) {
+                    const float* g = &w[((size_t)co * 128 + ci) * 9];
+                    for (int pp = 0; pp < 5; pp++)
+                        for (int qq = 0; qq < 5; qq++) {
+                            double u = 0.0;
+                            for (int ky = 0; ky < 3; ky++)
+                                for (int kx = 0; kx < 3; kx++) u += G3[pp][ky] * G3[qq][kx] * (double)g[ky * 3 + kx];
+                            const int chunk = ci / 32, k = ci % 32;
+                            wu[((((size_t)chunk * 25 + pp * 5 + qq) * 128) + co) * 32 + k] = (float)(u * sc[co]);
+                        }
+                }
+            GOAI_HIP_CHECK(hipMemcpy(net.wt_wino3 + (size_t)l * 25 * 128 * 128, wu.data(), wu.size() * sizeof(float),
+                                     hipMemcpyHostToDevice));
+        }
+        if (net.wino_mode == 2) {
             // U = G g Gt per (cout, cin), G = (1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1), in fp64, BN scale folded
             static const double Gm[4][3] = { { 1, 0, 0 }, { 0.5, 0.5, 0.5 }, { 0.5, -0.5, 0.5 }, { 0, 0, 1 } };
             std::vector<float> wu((size_t)16 * 128 * 128);
@@ -278,6 +308,8 @@ static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const f
         return launch_conv3x3_bf16(c->S, in, (const uint16_t*)net.wt_bf16 + (size_t)l * WT_BF16_PER_CONV, b, resid, out, M,
                                    c->stream);
     const bool wino = net.wino_mode == 2;
+    if (net.wino_mode == 3)
+        return launch_conv3x3_wino3(c->S, in, net.wt_wino3 + (size_t)l * 25 * 128 * 128, b, resid, out, M / c->P, c->stream);
     if (wino)
         return launch_conv3x3_wino(c->S, in, net.wt_wino + (size_t)l * 16 * 128 * 128, b, resid, out, M / c->P, c->stream);
     return launch_conv3x3(c->S, in, net.wt + (size_t)l * 9 * 128 * 128, b, resid, out, M, c->stream);

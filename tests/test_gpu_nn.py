@@ -190,12 +190,33 @@ def test_load_weights_errors():
     c.close()
 
 
+@pytest.mark.parametrize("kind,n,layers,max_batch", [("ac", 333, 3, 128), ("ac", 1024, 3, 1024), ("val", 77, 3, 256),
+                                                     ("ac", 1, 3, 8), ("ac", 6, 10, 8)])
+def test_winograd_f3x3_forward_matches_torch_oracle(kind, n, layers, max_batch, monkeypatch):
+    """GOAI_CONV_ALGO=wino3: fp32 Winograd F(3x3,3x3) trunk for 9x9 (conv_wino3_kernels.hip), same fp32 bound."""
+    size = 9
+    monkeypatch.setenv("GOAI_CONV_ALGO", "wino3")
+    c, sd = make_ctx(kind, size, 100 + size + layers, layers, max_batch)
+    monkeypatch.delenv("GOAI_CONV_ALGO")
+    states = random_positions(size, n, seed=size * 7 + n, canonical=True, pass_prob=0.05)
+    want_pi, want_val = nn_ref.forward(sd, torch.tensor(states), kind)
+    pi, val = c.nn_forward(states, mode=c.NN_RAW)
+    ev = rel_err(val.cpu().numpy(), want_val.numpy())
+    ep = rel_err(pi.cpu().numpy(), want_pi.numpy()) if kind == "ac" else 0.0
+    print(f"wino3 {kind}{size} L{layers}: rel err val {ev:.2e} pi {ep:.2e}")
+    assert ev < REL_TOL and ep < REL_TOL
+    k = min(n, 5)
+    _, val_k = c.nn_forward(states[:k], mode=c.NN_RAW)
+    assert np.array_equal(val_k.cpu().numpy(), val.cpu().numpy()[:k])
+    c.close()
+
+
 def test_conv_algorithm_is_fixed_per_context(monkeypatch):
     """goai_nn_init picks the trunk kernel once, from max_batch (Winograd when its workgroups fill
     the chip, boards >= 9x9), so a position's output does not depend on its batch."""
     from go_ai.engine import Context
     monkeypatch.delenv("GOAI_CONV_ALGO", raising=False)
-    for size, max_batch, want in [(9, 1024, Context.CONV_WINOGRAD), (9, 64, Context.CONV_DIRECT),
+    for size, max_batch, want in [(9, 1024, Context.CONV_WINOGRAD_F3), (9, 64, Context.CONV_DIRECT), (13, 512, Context.CONV_WINOGRAD),
                                   (5, 4096, Context.CONV_DIRECT), (19, 512, Context.CONV_WINOGRAD)]:
         c = Context(size)
         c.nn_init(Context.NET_AC, 3, max_batch)
@@ -206,7 +227,7 @@ def test_conv_algorithm_is_fixed_per_context(monkeypatch):
     assert c.nn_conv_algo() == Context.CONV_BF16X3
     c.close()
     c, sd = make_ctx("ac", 9, 5, 3, 1024)
-    assert c.nn_conv_algo() == Context.CONV_WINOGRAD
+    assert c.nn_conv_algo() == Context.CONV_WINOGRAD_F3
     states = random_positions(9, 300, seed=3, canonical=True, pass_prob=0.05)
     pi, val = c.nn_forward(states, mode=c.NN_RAW)
     pi1, val1 = c.nn_forward(states[7:8], mode=c.NN_RAW)

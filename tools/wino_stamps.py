@@ -13,7 +13,7 @@ for _ in range(3): c.nn_forward(st)
 torch.cuda.synchronize()
 n = int(os.environ.get("NWG", "256"))
 buf = (ctypes.c_ulonglong * (8 * n))()
-_hip.lib.goai_debug_wino_stamps(buf, 8 * n)
+getattr(_hip.lib, "goai_debug_wino3_stamps" if os.environ.get("GOAI_CONV_ALGO") == "wino3" else "goai_debug_wino_stamps")(buf, 8 * n)
 a = np.array(buf, dtype=np.int64).reshape(n, 8)
 t0 = a[:, 0].min()
 t = (a[:, :6] - t0) / 100.0
@@ -23,4 +23,4 @@ pr(names[0], t[:, 0])
 for i in range(1, 6): pr(names[i], t[:, i] - t[:, i - 1])
 pr("end", t[:, 5])
 cyc = (a[:, 7] - a[:, 6]).astype(float); us = (a[:, 4] - a[:, 1]) / 100.0
-print(f"main loop: {np.median(cyc):.0f} shader cycles in {np.median(us):.1f} us -> in-kernel clock {np.median(cyc / us) / 1e3:.3f} GHz; {np.median(cyc) / 64:.0f} cycles per stage (MFMA pipe needs 3584)")
+print(f"main loop: {np.median(cyc):.0f} shader cycles in {np.median(us):.1f} us -> in-kernel clock {np.median(cyc / us) / 1e3:.3f} GHz; {np.median(cyc) / 64:.0f} cycles per 1/64 of the loop (MFMA pipe needs 3584 for F(2x2,3x3), 1536 for F(3x3,3x3))")
