@@ -180,7 +180,10 @@ def main():
         executed_flop = 2.0 * wgs * 112 * 16 * 128 * 128
     elif algo == 3:
         # Winograd F(3x3,3x3): 25 products per 3x3 output tile; workgroups of 48 tile rows = 4 boards of 9x9
-        wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // 4)
+        # (5 boards once 4 per workgroup would need more than one round of CUs)
+        nb = int(round(conv_rows / (SIZE * SIZE)))
+        n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        wgs = -(-nb // 4) if -(-nb // 4) <= n_cu else -(-nb // 5)
         executed_flop = 2.0 * wgs * 48 * 25 * 128 * 128
 
     # the one collective of the run: gather per-rank results (utils.py:201-204's allreduces)

@@ -28,11 +28,11 @@ namespace goai {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int S>
+template <int S, int NBW_>
 struct Wino3 {
     static_assert(S % 3 == 0, "F(3x3,3x3) tiles must cover the board exactly");
     static constexpr int T = S / 3, T2 = T * T, P = S * S;
-    static constexpr int NBW = 4;                                  // whole boards per workgroup
+    static constexpr int NBW = NBW_;                               // whole boards per workgroup (4 or 5 at 9x9)
     static constexpr int WT = NBW * T2;                            // real wtiles per workgroup
     static constexpr int MT = (WT + 15) / 16, ROWS = MT * 16;      // MFMA row tiles
     static constexpr int IMG_U4 = NBW * P * 8 + 8;                 // 16-byte units (+ the zero cell)
@@ -58,13 +58,13 @@ extern "C" int goai_debug_wino3_stamps(unsigned long long* host_out, int n)
 
 __device__ __forceinline__ int w3swz(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
 
-template <int S, bool RESID>
+template <int S, int NBW, bool RESID>
 __global__ __launch_bounds__(512) void k_conv3x3_wino3(const float* __restrict__ in, const float* __restrict__ wt,
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ out,
                                                        int nboards)
 {
-    using W = Wino3<S>;
+    using W = Wino3<S, NBW>;
     constexpr int P = W::P, MT = W::MT, ROWS = W::ROWS;
     __shared__ f32x4 lds[W::LDS_U4];
     f32x4* Img = lds;
@@ -89,9 +89,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(const float* __restrict__
         Tab[e] = (uint16_t)((ok ? (bl * P + y * S + x) * 8 : W::ZERO_U4) * 16);
     }
 
-    // input-transform job of this thread: lanes 0..8 of every 16 take one (wtile, channel slot) item
-    const int item = (tid >> 4) * 9 + (tid & 15);
-    const bool t_on = (tid & 15) < 9 && item < W::WT * 8;
+    // input-transform job of this thread: WT * 8 (wtile, channel slot) items spread evenly over the
+    // eight waves, lanes 0..LPG-1 of every 16 take one
+    constexpr int LPG = (W::WT * 8 + 31) / 32;
+    static_assert(LPG <= 16, "too many wtiles for one transform pass");
+    const int item = (tid >> 4) * LPG + (tid & 15);
+    const bool t_on = (tid & 15) < LPG && item < W::WT * 8;
     const int ts = item & 7, ttw = t_on ? item >> 3 : 0;
 
     f32x4 ireg[W::NI];
@@ -282,20 +285,31 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(const float* __restrict__
 }
 
 int wino3_supported(int S_rt) { return S_rt == 9; }
-int wino3_boards_per_wg(int S_rt) { return S_rt == 9 ? Wino3<9>::NBW : 1; }
+int wino3_boards_per_wg(int S_rt) { return S_rt == 9 ? 4 : 1; }
 
+template <int NBW>
+static int launch_wino3_9(const float* in, const float* wt_wino3, const float* bias, const float* resid, float* out,
+                          int nboards, hipStream_t st)
+{
+    const int grid = (nboards + NBW - 1) / NBW;
+    if (resid) k_conv3x3_wino3<9, NBW, true><<<dim3(grid), dim3(512), 0, st>>>(in, wt_wino3, bias, resid, out, nboards);
+    else k_conv3x3_wino3<9, NBW, false><<<dim3(grid), dim3(512), 0, st>>>(in, wt_wino3, bias, resid, out, nboards);
+    GOAI_HIP_CHECK(hipGetLastError());
+    return GOAI_OK;
+}
+
+// A workgroup costs the same whether 36 or 45 of its 48 tile rows are real: 4 boards per workgroup
+// while that fits one round of the chip, else 5 (20 % fewer workgroups).  A board's result does not
+// depend on the choice (every tile row is computed independently, in the same order).
 int launch_conv3x3_wino3(int S_rt, const float* in, const float* wt_wino3, const float* bias, const float* resid,
-                         float* out, int nboards, hipStream_t st)
+                         float* out, int nboards, int n_cu, hipStream_t st)
 {
     if (S_rt != 9) {
         set_error("the F(3x3,3x3) convolution is built for 9x9 boards");
         return GOAI_ERR_ARG;
     }
-    const int grid = (nboards + Wino3<9>::NBW - 1) / Wino3<9>::NBW;
-    if (resid) k_conv3x3_wino3<9, true><<<dim3(grid), dim3(512), 0, st>>>(in, wt_wino3, bias, resid, out, nboards);
-    else k_conv3x3_wino3<9, false><<<dim3(grid), dim3(512), 0, st>>>(in, wt_wino3, bias, resid, out, nboards);
-    GOAI_HIP_CHECK(hipGetLastError());
-    return GOAI_OK;
+    if ((nboards + 3) / 4 <= n_cu) return launch_wino3_9<4>(in, wt_wino3, bias, resid, out, nboards, st);
+    return launch_wino3_9<5>(in, wt_wino3, bias, resid, out, nboards, st);
 }
 
 }  // namespace goai

@@ -48,7 +48,7 @@ int wino_boards_per_wg(int S);
 int wino3_supported(int S);
 int wino3_boards_per_wg(int S);
 int launch_conv3x3_wino3(int S, const float* in, const float* wt_wino3, const float* bias, const float* resid, float* out,
-                         int nboards, hipStream_t st);
+                         int nboards, int n_cu, hipStream_t st);
 int launch_conv3x3_wino(int S, const float* in, const float* wt_wino, const float* bias, const float* resid, float* out,
                         int nboards, hipStream_t st);
 int launch_heads(int S, const float* act, const HeadWeights& hw, int is_ac, float* pi, float* val, int nboards,

@@ -309,7 +309,7 @@ static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const f
                                    c->stream);
     const bool wino = net.wino_mode == 2;
     if (net.wino_mode == 3)
-        return launch_conv3x3_wino3(c->S, in, net.wt_wino3 + (size_t)l * 25 * 128 * 128, b, resid, out, M / c->P, c->stream);
+        return launch_conv3x3_wino3(c->S, in, net.wt_wino3 + (size_t)l * 25 * 128 * 128, b, resid, out, M / c->P, net.n_cu, c->stream);
     if (wino)
         return launch_conv3x3_wino(c->S, in, net.wt_wino + (size_t)l * 16 * 128 * 128, b, resid, out, M / c->P, c->stream);
     return launch_conv3x3(c->S, in, net.wt + (size_t)l * 9 * 128 * 128, b, resid, out, M, c->stream);

@@ -191,7 +191,8 @@ def test_load_weights_errors():
 
 
 @pytest.mark.parametrize("kind,n,layers,max_batch", [("ac", 333, 3, 128), ("ac", 1024, 3, 1024), ("val", 77, 3, 256),
-                                                     ("ac", 1, 3, 8), ("ac", 6, 10, 8)])
+                                                     ("ac", 1, 3, 8), ("ac", 6, 10, 8),
+                                                     ("ac", 1500, 3, 2048)])   # > 1024 boards: 5 boards per workgroup
 def test_winograd_f3x3_forward_matches_torch_oracle(kind, n, layers, max_batch, monkeypatch):
     """GOAI_CONV_ALGO=wino3: fp32 Winograd F(3x3,3x3) trunk for 9x9 (conv_wino3_kernels.hip), same fp32 bound."""
     size = 9
