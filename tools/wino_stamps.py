@@ -13,7 +13,7 @@ for _ in range(3): c.nn_forward(st)
 torch.cuda.synchronize()
 n = int(os.environ.get("NWG", "256"))
 buf = (ctypes.c_ulonglong * (8 * n))()
-getattr(_hip.lib, "goai_debug_wino3_stamps" if os.environ.get("GOAI_CONV_ALGO") == "wino3" else "goai_debug_wino_stamps")(buf, 8 * n)
+getattr(_hip.lib, os.environ.get("STAMP_SYM", "goai_debug_wino3_stamps" if os.environ.get("GOAI_CONV_ALGO") == "wino3" else "goai_debug_wino_stamps"))(buf, 8 * n)
 a = np.array(buf, dtype=np.int64).reshape(n, 8)
 t0 = a[:, 0].min()
 t = (a[:, :6] - t0) / 100.0
