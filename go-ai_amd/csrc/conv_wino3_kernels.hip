@@ -38,7 +38,7 @@ struct Wino3 {
     static constexpr int IMG_U4 = NBW * P * 8 + 8;                 // 16-byte units (+ the zero cell)
     static constexpr int ZERO_U4 = NBW * P * 8;
     static constexpr int V_U4 = 5 * ROWS * 8;                      // one buffer: [5 q][ROWS][32 ch]
-    static constexpr int TAB_U4 = WT * 5;                          // [wtile][a] -> 8 x u16 (5 used)
+    static constexpr int TAB_U4 = WT * 8 * 5;                      // [wtile][slot][a] -> 8 x u16 (5 used): final LDS byte addresses
     static constexpr int NI = (NBW * P * 8 + 511) / 512;
     static constexpr int LDS_U4 = IMG_U4 + 2 * V_U4 + TAB_U4;
     static_assert(LDS_U4 * 16 <= 160 * 1024, "LDS budget");
@@ -62,14 +62,14 @@ template <int S, int NBW, bool RESID>
 __global__ __launch_bounds__(512) void k_conv3x3_wino3(const float* __restrict__ in, const float* __restrict__ wt,
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ out,
-                                                       int nboards)
+                                                       const uint4* __restrict__ tab_g, int nboards)
 {
     using W = Wino3<S, NBW>;
     constexpr int P = W::P, MT = W::MT, ROWS = W::ROWS;
     __shared__ f32x4 lds[W::LDS_U4];
     f32x4* Img = lds;
     f32x4* Vs = lds + W::IMG_U4;
-    uint16_t* Tab = reinterpret_cast<uint16_t*>(lds + W::IMG_U4 + 2 * W::V_U4);
+    uint4* Tab = reinterpret_cast<uint4*>(lds + W::IMG_U4 + 2 * W::V_U4);
 
     W3_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,16 +78,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(const float* __restrict__
 
     for (int i = tid; i < 2 * W::V_U4; i += 512) Vs[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };   // rows >= WT stay zero
     if (tid < 8) Img[W::ZERO_U4 + tid] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-    // Tab[tw][a][b] = byte address in Img (slot 0, before the slot swizzle) of cell (3ty - 1 + a,
-    // 3tx - 1 + b) of wtile tw's 5x5 input patch, or of the zero cell when that is off the board
-    for (int e = tid; e < W::WT * 40; e += 512) {
-        const int tw = e / 40, a = (e % 40) >> 3, b = e & 7;
-        const int bl = tw / W::T2, rem = tw - bl * W::T2;
-        const int ty = rem / W::T, tx = rem - ty * W::T;
-        const int y = 3 * ty - 1 + a, x = 3 * tx - 1 + b;
-        const bool ok = b < 5 && y >= 0 && y < S && x >= 0 && x < S;
-        Tab[e] = (uint16_t)((ok ? (bl * P + y * S + x) * 8 : W::ZERO_U4) * 16);
-    }
+    // Tab[tw][slot][a] = the five LDS byte addresses (u16) of row a of wtile tw's 5x5 input patch for
+    // channel slot `slot`, slot swizzle applied, off-board cells redirected to the zero cell: built once
+    // on the host (wino3_build_table), so a patch read costs one unpack and no address arithmetic
+    for (int e = tid; e < W::TAB_U4; e += 512) Tab[e] = tab_g[e];
 
     // input-transform job of this thread: WT * 8 (wtile, channel slot) items spread evenly over the
     // eight waves, lanes 0..LPG-1 of every 16 take one
@@ -118,13 +112,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(const float* __restrict__
         }
     };
     auto img_at = [&](uint32_t byte_addr) -> f32x4 {
-        const uint32_t cell = byte_addr >> 7;          // the zero cell: every slot is zero
-        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Img) + byte_addr +
-                                               ((ts ^ ((cell >> 1) & 7)) << 4));
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Img) + byte_addr);
     };
     // one row of the patch (a), the five cells b = 0..4
+    const uint4* tabrow = Tab + (ttw * 8 + ts) * 5;
     auto patch_row = [&](int a, f32x4* d) {
-        const uint4 t = *reinterpret_cast<const uint4*>(&Tab[ttw * 40 + a * 8]);
+        const uint4 t = tabrow[a];
         d[0] = img_at(t.x & 0xffffu);
         d[1] = img_at(t.x >> 16);
         d[2] = img_at(t.y & 0xffffu);
@@ -289,11 +282,12 @@ int wino3_boards_per_wg(int S_rt) { return S_rt == 9 ? 4 : 1; }
 
 template <int NBW>
 static int launch_wino3_9(const float* in, const float* wt_wino3, const float* bias, const float* resid, float* out,
-                          int nboards, hipStream_t st)
+                          const void* tab, int nboards, hipStream_t st)
 {
     const int grid = (nboards + NBW - 1) / NBW;
-    if (resid) k_conv3x3_wino3<9, NBW, true><<<dim3(grid), dim3(512), 0, st>>>(in, wt_wino3, bias, resid, out, nboards);
-    else k_conv3x3_wino3<9, NBW, false><<<dim3(grid), dim3(512), 0, st>>>(in, wt_wino3, bias, resid, out, nboards);
+    const uint4* tg = reinterpret_cast<const uint4*>(tab);
+    if (resid) k_conv3x3_wino3<9, NBW, true><<<dim3(grid), dim3(512), 0, st>>>(in, wt_wino3, bias, resid, out, tg, nboards);
+    else k_conv3x3_wino3<9, NBW, false><<<dim3(grid), dim3(512), 0, st>>>(in, wt_wino3, bias, resid, out, tg, nboards);
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }
@@ -301,15 +295,35 @@ static int launch_wino3_9(const float* in, const float* wt_wino3, const float* b
 // A workgroup costs the same whether 36 or 45 of its 48 tile rows are real: 4 boards per workgroup
 // while that fits one round of the chip, else 5 (20 % fewer workgroups).  A board's result does not
 // depend on the choice (every tile row is computed independently, in the same order).
+// Host side of the input-transform address table for `nbw` boards per workgroup (4 or 5):
+// out[((tw * 8 + slot) * 5 + a) * 8 + b], b < 5; returns the number of uint16 entries.
+size_t wino3_build_table(int S_rt, int nbw, uint16_t* out)
+{
+    const int S = S_rt, T = S / 3, T2 = T * T, P = S * S, WT = nbw * T2, zero_u4 = nbw * P * 8;
+    if (out)
+        for (int tw = 0; tw < WT; tw++)
+            for (int slot = 0; slot < 8; slot++)
+                for (int a = 0; a < 5; a++)
+                    for (int b = 0; b < 8; b++) {
+                        const int bl = tw / T2, rem = tw % T2, ty = rem / T, tx = rem % T;
+                        const int y = 3 * ty - 1 + a, x = 3 * tx - 1 + b;
+                        const bool ok = b < 5 && y >= 0 && y < S && x >= 0 && x < S;
+                        const int cell = bl * P + y * S + x;
+                        const int u4 = ok ? cell * 8 + (slot ^ ((cell >> 1) & 7)) : zero_u4 + slot;
+                        out[(((size_t)tw * 8 + slot) * 5 + a) * 8 + b] = (uint16_t)(u4 * 16);
+                    }
+    return (size_t)WT * 8 * 5 * 8;
+}
+
 int launch_conv3x3_wino3(int S_rt, const float* in, const float* wt_wino3, const float* bias, const float* resid,
-                         float* out, int nboards, int n_cu, hipStream_t st)
+                         float* out, const void* const* tabs, int nboards, int n_cu, hipStream_t st)
 {
     if (S_rt != 9) {
         set_error("the F(3x3,3x3) convolution is built for 9x9 boards");
         return GOAI_ERR_ARG;
     }
-    if ((nboards + 3) / 4 <= n_cu) return launch_wino3_9<4>(in, wt_wino3, bias, resid, out, nboards, st);
-    return launch_wino3_9<5>(in, wt_wino3, bias, resid, out, nboards, st);
+    if ((nboards + 3) / 4 <= n_cu) return launch_wino3_9<4>(in, wt_wino3, bias, resid, out, tabs[0], nboards, st);
+    return launch_wino3_9<5>(in, wt_wino3, bias, resid, out, tabs[1], nboards, st);
 }
 
 }  // namespace goai

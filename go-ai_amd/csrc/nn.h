@@ -30,6 +30,7 @@ struct Net {
     float* wt_wino = nullptr;  // f32 Winograd F(2x2,3x3): [2*layers][4 chunks][16 xi][128 out][32 in] = G g Gt (null: direct only)
     int wino_mode = 0;         // 0: direct kernel, 2: Winograd F(2x2,3x3), 3: Winograd F(3x3,3x3) (chosen in nn_init)
     float* wt_wino3 = nullptr; // F(3x3,3x3): [2*layers][4 chunks][25 xi][128 out][32 in]
+    void* wino3_tab[2] = { nullptr, nullptr };   // input-transform address tables for 4 / 5 boards per workgroup
     int n_cu = 256;
     void* wt_bf16 = nullptr;   // bf16x3: [2*layers][4 chunks][9 taps][128 out][32 hi | 32 lo]
     float* bt = nullptr;       // [2*layers][128]
@@ -47,8 +48,9 @@ int launch_conv3x3_bf16(int S, const float* in, const void* wt_bf16, const float
 int wino_boards_per_wg(int S);
 int wino3_supported(int S);
 int wino3_boards_per_wg(int S);
+size_t wino3_build_table(int S, int nbw, uint16_t* out);
 int launch_conv3x3_wino3(int S, const float* in, const float* wt_wino3, const float* bias, const float* resid, float* out,
-                         int nboards, int n_cu, hipStream_t st);
+                         const void* const* tabs, int nboards, int n_cu, hipStream_t st);
 int launch_conv3x3_wino(int S, const float* in, const float* wt_wino, const float* bias, const float* resid, float* out,
                         int nboards, hipStream_t st);
 int launch_heads(int S, const float* act, const HeadWeights& hw, int is_ac, float* pi, float* val, int nboards,

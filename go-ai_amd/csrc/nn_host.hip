@@ -90,8 +90,15 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
         }
         if (n.wino_mode == 2 && (rc = dev_alloc(c, (void**)&n.wt_wino, (size_t)2 * layers * 16 * 128 * 128 * sizeof(float))))
             return rc;
-        if (n.wino_mode == 3 && (rc = dev_alloc(c, (void**)&n.wt_wino3, (size_t)2 * layers * 25 * 128 * 128 * sizeof(float))))
-            return rc;
+        if (n.wino_mode == 3) {
+            if ((rc = dev_alloc(c, (void**)&n.wt_wino3, (size_t)2 * layers * 25 * 128 * 128 * sizeof(float)))) return rc;
+            for (int i = 0; i < 2; i++) {
+                std::vector<uint16_t> tab(wino3_build_table(c->S, 4 + i, nullptr));
+                wino3_build_table(c->S, 4 + i, tab.data());
+                if ((rc = dev_alloc(c, &n.wino3_tab[i], tab.size() * sizeof(uint16_t)))) return rc;
+                GOAI_HIP_CHECK(hipMemcpy(n.wino3_tab[i], tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            }
+        }
         if (dtype == GOAI_DTYPE_BF16X3) {
             if ((rc = dev_alloc(c, &n.wt_bf16, (size_t)2 * layers * WT_BF16_PER_CONV * sizeof(uint16_t)))) return rc;
         } else if ((rc = dev_alloc(c, (void**)&n.wt, (size_t)2 * layers * 9 * 128 * 128 * sizeof(float)))) return rc;
@@ -309,7 +316,7 @@ static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const f
                                    c->stream);
     const bool wino = net.wino_mode == 2;
     if (net.wino_mode == 3)
-        return launch_conv3x3_wino3(c->S, in, net.wt_wino3 + (size_t)l * 25 * 128 * 128, b, resid, out, M / c->P, net.n_cu, c->stream);
+        return launch_conv3x3_wino3(c->S, in, net.wt_wino3 + (size_t)l * 25 * 128 * 128, b, resid, out, net.wino3_tab, M / c->P, net.n_cu, c->stream);
     if (wino)
         return launch_conv3x3_wino(c->S, in, net.wt_wino + (size_t)l * 16 * 128 * 128, b, resid, out, M / c->P, c->stream);
     return launch_conv3x3(c->S, in, net.wt + (size_t)l * 9 * 128 * 128, b, resid, out, M, c->stream);
