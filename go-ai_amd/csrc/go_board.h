@@ -82,20 +82,37 @@ __device__ __forceinline__ void board_analyze(BoardLds<S>& L)
         if (idx < G::P) { int q = cell_q<S>(idx); L.lab[q] = (uint16_t)q; L.aux[q] = 0; }
     }
     __syncthreads();
+    // Colours do not change during the propagation: which neighbours belong to the cell's component
+    // is decided once, and every sweep then issues its five label reads back to back (no branches
+    // around LDS reads: a chain of dependent conditional reads was most of this function's time).
+    int qs[G::K];
+    uint32_t same[G::K];
+#pragma unroll
+    for (int k = 0; k < G::K; k++) {
+        const int idx = lane + 64 * k;
+        qs[k] = -1;
+        same[k] = 0;
+        if (idx < G::P) {
+            const int q = cell_q<S>(idx);
+            const uint8_t c = L.col[q], c0 = L.col[q - 1], c1 = L.col[q + 1], c2 = L.col[q - G::PS], c3 = L.col[q + G::PS];
+            qs[k] = q;
+            same[k] = (c0 == c ? 1u : 0u) | (c1 == c ? 2u : 0u) | (c2 == c ? 4u : 0u) | (c3 == c ? 8u : 0u);
+        }
+    }
     bool any_changed;
     do {
         bool ch = false;
 #pragma unroll
         for (int k = 0; k < G::K; k++) {
-            int idx = lane + 64 * k;
-            if (idx < G::P) {
-                int q = cell_q<S>(idx);
-                uint8_t c = L.col[q];
-                int cur = L.lab[q], m = cur;
-                if (L.col[q - 1] == c) m = min(m, (int)L.lab[q - 1]);
-                if (L.col[q + 1] == c) m = min(m, (int)L.lab[q + 1]);
-                if (L.col[q - G::PS] == c) m = min(m, (int)L.lab[q - G::PS]);
-                if (L.col[q + G::PS] == c) m = min(m, (int)L.lab[q + G::PS]);
+            if (qs[k] >= 0) {
+                const int q = qs[k];
+                const int cur = L.lab[q];
+                const int l0 = L.lab[q - 1], l1 = L.lab[q + 1], l2 = L.lab[q - G::PS], l3 = L.lab[q + G::PS];
+                int m = cur;
+                m = (same[k] & 1u) ? min(m, l0) : m;
+                m = (same[k] & 2u) ? min(m, l1) : m;
+                m = (same[k] & 4u) ? min(m, l2) : m;
+                m = (same[k] & 8u) ? min(m, l3) : m;
                 m = L.lab[m];   // pointer jump: lab[m] <= m and lies in the same component
                 if (m < cur) { L.lab[q] = (uint16_t)m; ch = true; }
             }
@@ -106,18 +123,18 @@ __device__ __forceinline__ void board_analyze(BoardLds<S>& L)
 
 #pragma unroll
     for (int k = 0; k < G::K; k++) {
-        int idx = lane + 64 * k;
-        if (idx < G::P) {
-            int q = cell_q<S>(idx);
-            uint8_t c = L.col[q];
+        if (qs[k] >= 0) {
+            const int q = qs[k];
+            const uint8_t c = L.col[q];
             const int nq[4] = { q - 1, q + 1, q - G::PS, q + G::PS };
+            uint8_t cn[4];
+            int ln[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { cn[i] = L.col[nq[i]]; ln[i] = L.lab[nq[i]]; }   // (border labels are never used)
             if (c == 0) {
                 int r[4];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    uint8_t cn = L.col[nq[i]];
-                    r[i] = (cn == 1 || cn == 2) ? (int)L.lab[nq[i]] : -1;
-                }
+                for (int i = 0; i < 4; i++) r[i] = (cn[i] == 1 || cn[i] == 2) ? ln[i] : -1;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     bool dup = r[i] < 0;
@@ -128,7 +145,7 @@ __device__ __forceinline__ void board_analyze(BoardLds<S>& L)
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                    if (L.col[nq[i]] == 0) atomicOr(&L.aux[L.lab[nq[i]]], (uint32_t)c);
+                    if (cn[i] == 0) atomicOr(&L.aux[ln[i]], (uint32_t)c);
             }
         }
     }
@@ -172,16 +189,25 @@ __device__ __forceinline__ void board_invalid(BoardLds<S>& L, int next_col, int 
         bool bad = false;
         if (idx < G::P) {
             int q = cell_q<S>(idx);
+            const int nq[4] = { q - 1, q + 1, q - G::PS, q + G::PS };
+            uint8_t cn[4];
+            uint32_t an[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) cn[i] = L.col[nq[i]];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {                    // liberties of the neighbouring group (own cell for non-stones)
+                const int lb = L.lab[nq[i]];
+                const int root = (cn[i] == 1 || cn[i] == 2) ? lb : q;
+                an[i] = L.aux[root];
+            }
             if (L.col[q] != 0 || q == ko_q) bad = true;
             else {
-                const int nq[4] = { q - 1, q + 1, q - G::PS, q + G::PS };
                 bool ok = false;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    uint8_t cn = L.col[nq[i]];
-                    if (cn == 0) ok = true;
-                    else if (cn == next_col) ok = ok || (L.aux[L.lab[nq[i]]] >= 2u);
-                    else if (cn == other) ok = ok || (L.aux[L.lab[nq[i]]] == 1u);
+                    if (cn[i] == 0) ok = true;
+                    else if (cn[i] == next_col) ok = ok || (an[i] >= 2u);
+                    else if (cn[i] == other) ok = ok || (an[i] == 1u);
                 }
                 bad = !ok;
             }
