@@ -3,6 +3,8 @@
 #include <string>
 
 #include "ctx.h"
+#include <vector>
+
 #include "goai_internal.h"
 
 namespace goai {
@@ -264,7 +266,16 @@ int goai_mcts_counters(goai_ctx* ctx, int64_t* counters_host)
     CTX_ENTER(ctx);
     GOAI_REQUIRE(ctx->tree.n_games > 0 && counters_host, "call goai_mcts_init first / NULL output");
     GOAI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    GOAI_HIP_CHECK(hipMemcpy(counters_host, ctx->tree.counters, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    // one slot per counter and game on the device (a single address would serialise n_games atomics
+    // per kernel at the memory side): summed here
+    const size_t G = (size_t)ctx->tree.n_games;
+    std::vector<int64_t> slots(4 * G);
+    GOAI_HIP_CHECK(hipMemcpy(slots.data(), ctx->tree.counters, slots.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; k++) {
+        int64_t sum = 0;
+        for (size_t g = 0; g < G; g++) sum += slots[k * G + g];
+        counters_host[k] = sum;
+    }
     return GOAI_OK;
 }
 

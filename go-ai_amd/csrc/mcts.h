@@ -46,7 +46,7 @@ struct Tree {
     float* pi_logits = nullptr;       // [G][A]
     float* val_logits = nullptr;      // [G]
     double* sqrt_tab = nullptr;       // sqrt(i), i <= max_sims + 1, rounded on the host
-    unsigned long long* counters = nullptr;   // [0] leaf evals, [1] transitions, [2] errors, [3] states sent through the net
+    unsigned long long* counters = nullptr;   // [4][n_games]: [0] leaf evals, [1] transitions, [2] errors, [3] states sent through the net
     // Q mode (mct.py:44-47): per step, the leaf of every game and its valid children form one
     // compacted evaluation batch: game g owns entries [q_off[g], q_off[g+1]) = leaf, children
     // in ascending action order

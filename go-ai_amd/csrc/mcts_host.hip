@@ -48,7 +48,7 @@ int mcts_init(goai_ctx* c, int n_games, int max_sims, int mode)
     AL(turn, G); AL(moves, G); AL(result, G);
     AL(leaf_planes, G * 6 * P); AL(pi_logits, G * A); AL(val_logits, G);
     AL(sqrt_tab, (size_t)max_sims + 2);
-    AL(counters, 4);
+    AL(counters, 4 * G);
     if (mode == GOAI_SEARCH_Q) {
         AL(nval, N);
         AL(q_cnt, G); AL(q_off, G + 1);
@@ -61,7 +61,7 @@ int mcts_init(goai_ctx* c, int n_games, int max_sims, int mode)
     std::vector<double> tab(max_sims + 2);
     for (int i = 0; i < max_sims + 2; i++) tab[i] = std::sqrt((double)i);   // IEEE correctly rounded on the host
     GOAI_HIP_CHECK(hipMemcpy(t.sqrt_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
-    GOAI_HIP_CHECK(hipMemset(t.counters, 0, 4 * sizeof(unsigned long long)));
+    GOAI_HIP_CHECK(hipMemset(t.counters, 0, 4 * G * sizeof(unsigned long long)));
     GOAI_HIP_CHECK(hipMemset(t.visits, 0, N * sizeof(int32_t)));
     t.n_games = n_games;
     t.steps_since_reset = -1;   // no roots yet

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict_
         const int rc = board_next_state<S>(L, me, opp, inv, (uint32_t)(meta & 7u), act, nme, nopp, ninv, nflags, sgn);
         const int idx = t.nnodes[g];
         if (rc != 0 || idx >= t.ncap) {          // cannot happen for a consistent tree; never write out of bounds
-            if (lane == 0) atomicAdd(&t.counters[2], 1ull);
+            if (lane == 0) atomicAdd(&t.counters[(size_t)2 * t.n_games + g], 1ull);
             edge = -1;                           // evaluate the parent again rather than corrupt the tree
         } else {
             meta = pack_meta(nflags, sgn);
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict_
                 t.child[edge] = idx;
                 t.nnodes[g] = idx + 1;
                 path[d + 1] = idx;
-                atomicAdd(&t.counters[1], 1ull);
+                atomicAdd(&t.counters[(size_t)1 * t.n_games + g], 1ull);
             }
 #pragma unroll
             for (int k = 0; k < G::K; k++) { me[k] = nme[k]; opp[k] = nopp[k]; inv[k] = ninv[k]; }
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict_
     if (lane == 0) {
         t.leaf[g] = cur;
         t.depth[g] = d;
-        if (t.result[g] == 2) atomicAdd(&t.counters[0], 1ull);
+        if (t.result[g] == 2) atomicAdd(&t.counters[(size_t)0 * t.n_games + g], 1ull);
         // a non-terminal leaf is expanded by this step's second half: give it its row now
         const bool expand = !(meta & FLAG_DONE);
         if (expand && t.rowof[nb + cur] < 0) {
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict_
                 t.rowof[nb + cur] = r;
                 t.nrows[g] = r + 1;
                 if (edge >= 0) t.crow[edge] = r;
-            } else atomicAdd(&t.counters[2], 1ull);
+            } else atomicAdd(&t.counters[(size_t)2 * t.n_games + g], 1ull);
         }
         if (t.q_cnt) {
             int nvalid = 1;                        // the pass
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64) void k_mcts_advance(Tree t, const int32_t* __re
         node_load<S>(t, nb, me, opp, inv, meta);
         const int rc = board_next_state<S>(L, me, opp, inv, (uint32_t)(meta & 7u), actions[g], nme, nopp, ninv, nflags, sgn);
         if (rc != 0) {
-            if (lane == 0) atomicAdd(&t.counters[2], 1ull);
+            if (lane == 0) atomicAdd(&t.counters[(size_t)2 * t.n_games + g], 1ull);
         } else if (lane == 0) {
             node_store<S>(t, nb, nme, nopp, ninv, pack_meta(nflags, sgn));
             const int nturn = t.turn[g] ^ 1, nmoves = t.moves[g] + 1;
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(64) void k_q_expand(Tree t, uint8_t* __restrict__ c
         int sgn = 0;
         const int rc = board_next_state<S>(L, me, opp, inv, (uint32_t)(meta & 7u), a, nme, nopp, ninv, nflags, sgn);
         if (rc != 0 || idx >= t.ncap) {
-            if (lane == 0) { atomicAdd(&t.counters[2], 1ull); t.child[(rb + lrow) * G::A + a] = -2; }
+            if (lane == 0) { atomicAdd(&t.counters[(size_t)2 * t.n_games + g], 1ull); t.child[(rb + lrow) * G::A + a] = -2; }
             __syncthreads();
             continue;
         }
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(64) void k_q_expand(Tree t, uint8_t* __restrict__ c
             t.visits[nb + idx] = 0;
             t.rowof[nb + idx] = -1;
             t.child[(rb + lrow) * G::A + a] = idx;
-            atomicAdd(&t.counters[1], 1ull);
+            atomicAdd(&t.counters[(size_t)1 * t.n_games + g], 1ull);
         }
         planes_store<S>(t.q_planes + (size_t)(off + 1 + j) * 6 * G::P, nme, nopp, ninv, 0, nflags);
         if (cout) planes_store<S>(cout, nme, nopp, ninv, 0, nflags);
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(64) void k_q_backup(Tree t, const double* __restric
     }
     if (lane == 0) {
         t.nnodes[g] += nvalid;
-        atomicAdd(&t.counters[3], (unsigned long long)(1 + nvalid));
+        atomicAdd(&t.counters[(size_t)3 * t.n_games + g], (unsigned long long)(1 + nvalid));
     }
 }
 
