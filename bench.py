@@ -162,11 +162,12 @@ def main():
     my_forwards = st["forwards"] - cnt0["forwards"]
     fwd0 = st["forwards"]
     conv_ms, conv_n = sp.profile_conv()
+    cpl = sp.ctx.nn_convs_per_launch()       # F(3x3,3x3) runs the whole trunk (2 * blocks convolutions) in one launch
     if cfg["search"] == "ac":
         conv_rows = n_games // len(sp.groups) * SIZE * SIZE
     else:   # data-dependent batch sizes: rows = states sent through the net during the profiled move
-        conv_rows = (sp.counters()["forwards"] - fwd0) * SIZE * SIZE / max(1, conv_n // (2 * LAYERS))
-    conv_flop = 2.0 * conv_rows * 128 * (9 * 128)                    # algorithmic: the convolution's own multiply-adds
+        conv_rows = (sp.counters()["forwards"] - fwd0) * SIZE * SIZE / max(1, conv_n * cpl // (2 * LAYERS))
+    conv_flop = 2.0 * conv_rows * 128 * (9 * 128) * cpl              # algorithmic: the convolutions' own multiply-adds
     achieved = conv_flop / (conv_ms / conv_n * 1e-3) / 1e12
     peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS / 3.0
     algo = sp.ctx.nn_conv_algo()
@@ -184,7 +185,7 @@ def main():
         nb = int(round(conv_rows / (SIZE * SIZE)))
         n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
         wgs = -(-nb // 4) if -(-nb // 4) <= n_cu else -(-nb // 5)
-        executed_flop = 2.0 * wgs * 48 * 25 * 128 * 128
+        executed_flop = 2.0 * wgs * 48 * 25 * 128 * 128 * cpl
 
     # the one collective of the run: gather per-rank results (utils.py:201-204's allreduces)
     from go_ai.sharding import gather_stats, reduce_stats
@@ -216,7 +217,7 @@ def main():
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "avg_launch_us": round(conv_ms / conv_n * 1e3, 2), "launches_timed": conv_n,
-                         "flop_per_launch": conv_flop,
+                         "flop_per_launch": conv_flop, "convs_per_launch": cpl,
                          "algorithm": {0: "direct implicit GEMM, fp32 MFMA", 1: "Winograd F(2x2,3x3), fp32 MFMA",
                                        2: "direct implicit GEMM, bf16 MFMA on hi+lo split operands",
                                        3: "Winograd F(3x3,3x3), fp32 MFMA"}[algo],

@@ -128,6 +128,13 @@ int goai_nn_conv_algo(goai_ctx* ctx)
     return ctx->net.wino_mode ? GOAI_CONV_WINOGRAD : GOAI_CONV_DIRECT;
 }
 
+int goai_nn_convs_per_launch(goai_ctx* ctx)
+{
+    GOAI_REQUIRE(ctx, "ctx is NULL");
+    GOAI_REQUIRE(ctx->net.kind >= 0, "call goai_nn_init first");
+    return (ctx->net.trunk_fused && ctx->net.layers > 0) ? 2 * ctx->net.layers : 1;
+}
+
 int goai_nn_forward(goai_ctx* ctx, const uint8_t* states, float* pi_logits, float* val_logits, int n, int mode)
 {
     CTX_ENTER(ctx);

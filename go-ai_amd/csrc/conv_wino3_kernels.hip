@@ -58,11 +58,19 @@ extern "C" int goai_debug_wino3_stamps(unsigned long long* host_out, int n)
 
 __device__ __forceinline__ int w3swz(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
 
-template <int S, int NBW, bool RESID>
-__global__ __launch_bounds__(512) void k_conv3x3_wino3(const float* __restrict__ in, const float* __restrict__ wt,
-                                                       const float* __restrict__ bias,
-                                                       const float* __restrict__ resid, float* __restrict__ out,
-                                                       const uint4* __restrict__ tab_g, int nboards)
+// One launch runs `n_convs` convolutions in a row on the same boards (a workgroup owns whole boards
+// and all 128 output channels, so consecutive layers need no exchange between workgroups):
+//   conv k reads  (k even ? x : y),  writes (k even ? y : x),  adds the residual (k even ? resid0 : x)
+// i.e. n_convs = 1 is a single convolution x -> y (+ resid0, may be NULL), and an even n_convs with
+// resid0 = NULL is the whole residual trunk of n_convs / 2 BasicBlocks (models/__init__.py:234-251),
+// ending in x; the odd convolutions add and overwrite x in place (each lane reads the 16 bytes it is
+// about to write).  Layer k's weights / bias are at wt + k * 25 * 128 * 128 / bias + k * 128.
+// x and y are written and re-read inside the launch: no __restrict__ on them.
+template <int S, int NBW>
+__global__ __launch_bounds__(512) void k_conv3x3_wino3(float* x, float* y, const float* resid0,
+                                                       const float* __restrict__ wt_all,
+                                                       const float* __restrict__ bias_all,
+                                                       const uint4* __restrict__ tab_g, int nboards, int n_convs)
 {
     using W = Wino3<S, NBW>;
     constexpr int P = W::P, MT = W::MT, ROWS = W::ROWS;
@@ -75,6 +83,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int b_first = blockIdx.x * W::NBW;
+    const float* in = x;
+    const float* resid = resid0;
+    float* out = y;
 
     for (int i = tid; i < 2 * W::V_U4; i += 512) Vs[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };   // rows >= WT stay zero
     if (tid < 8) Img[W::ZERO_U4 + tid] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(const float* __restrict__
     };
 
     // weight fragments of a stage: U[stage][cout = 16 wave + li][32 in], k = kk*16 + lq*4 + jj
-    const float* wsrc = wt + (size_t)(wave * 16 + li) * 32 + lq * 4;
+    const float* wsrc = wt_all + (size_t)(wave * 16 + li) * 32 + lq * 4;
     f32x4 bcur[2], bnxt[2];
     auto load_b = [&](int stage, f32x4* b) {
         const float* src = wsrc + (size_t)stage * 128 * 32;
@@ -169,6 +180,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(const float* __restrict__
     };
 
     f32x4 Y[3][3][MT];                               // [i][j]: output (3ty + i, 3tx + j) of the wtile
+    const int tq = (wave < 4) ? 0 : 2;               // waves w and w + 4 share a SIMD: transform in different stages
+    const int col = wave * 16 + 4 * lq;
+
+#pragma unroll 1
+    for (int k = 0; k < n_convs; k++) {
+    const float* bias = bias_all + k * 128;
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -176,15 +193,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(const float* __restrict__
 #pragma unroll
             for (int t = 0; t < MT; t++) Y[i][j][t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 
-    load_img(0);
     load_b(0, bcur);
-    __syncthreads();                                 // the zero fills and the table are complete
+    // k = 0: the zero fills and the table are complete; k > 0: every wave's transforms of the previous
+    // convolution have ended and its stores to `in` are visible to this workgroup
+    __syncthreads();
+    load_img(0);
     store_img();
     __syncthreads();
     transform(0, 0);
     __syncthreads();
 
-    const int tq = (wave < 4) ? 0 : 2;               // waves w and w + 4 share a SIMD: transform in different stages
     W3_STAMP(1);
 #pragma unroll 1
     for (int chunk = 0; chunk < 4; chunk++) {
@@ -253,7 +271,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(const float* __restrict__
     // epilogue.  The products are formed transposed (A operand = weights, B operand = V), so in the
     // C/D layout of a 16x16 tile (col = lane & 15, row = 4 * (lane >> 4) + reg) a lane holds FOUR
     // CONSECUTIVE output channels of ONE wtile: one 16-byte load / store per output cell.
-    const int col = wave * 16 + 4 * lq;
     const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col]);
 #pragma unroll
     for (int t = 0; t < MT; t++) {
@@ -268,26 +285,29 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(const float* __restrict__
             for (int j = 0; j < 3; j++) {
                 const long off = (board * P + (3 * ty + i) * S + 3 * tx + j) * 128 + col;
                 f32x4 v = Y[i][j][t] + bv;
-                if (RESID) v += *reinterpret_cast<const f32x4*>(&resid[off]);
+                if (resid) v += *reinterpret_cast<const f32x4*>(&resid[off]);
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
                 *reinterpret_cast<f32x4*>(&out[off]) = v;
             }
     }
     W3_STAMP(5);
+    // next convolution of the launch: swap the buffers, step the weights
+    if (k & 1) { in = x; out = y; resid = resid0; } else { in = y; out = x; resid = x; }
+    wsrc += (size_t)25 * 128 * 128;
+    }
 }
 
 int wino3_supported(int S_rt) { return S_rt == 9; }
 int wino3_boards_per_wg(int S_rt) { return S_rt == 9 ? 4 : 1; }
 
 template <int NBW>
-static int launch_wino3_9(const float* in, const float* wt_wino3, const float* bias, const float* resid, float* out,
-                          const void* tab, int nboards, hipStream_t st)
+static int launch_wino3_9(float* x, float* y, const float* resid0, const float* wt_wino3, const float* bias,
+                          const void* tab, int nboards, int n_convs, hipStream_t st)
 {
     const int grid = (nboards + NBW - 1) / NBW;
     const uint4* tg = reinterpret_cast<const uint4*>(tab);
-    if (resid) k_conv3x3_wino3<9, NBW, true><<<dim3(grid), dim3(512), 0, st>>>(in, wt_wino3, bias, resid, out, tg, nboards);
-    else k_conv3x3_wino3<9, NBW, false><<<dim3(grid), dim3(512), 0, st>>>(in, wt_wino3, bias, resid, out, tg, nboards);
+    k_conv3x3_wino3<9, NBW><<<dim3(grid), dim3(512), 0, st>>>(x, y, resid0, wt_wino3, bias, tg, nboards, n_convs);
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }
@@ -315,15 +335,21 @@ size_t wino3_build_table(int S_rt, int nbw, uint16_t* out)
     return (size_t)WT * 8 * 5 * 8;
 }
 
-int launch_conv3x3_wino3(int S_rt, const float* in, const float* wt_wino3, const float* bias, const float* resid,
-                         float* out, const void* const* tabs, int nboards, int n_cu, hipStream_t st)
+// n_convs = 1: y = relu(conv(x) + bias (+ resid0)); n_convs even, resid0 = NULL: the residual trunk
+// in one launch, result in x (see the kernel's header)
+int launch_conv3x3_wino3(int S_rt, float* x, float* y, const float* resid0, const float* wt_wino3, const float* bias,
+                         const void* const* tabs, int nboards, int n_cu, int n_convs, hipStream_t st)
 {
     if (S_rt != 9) {
         set_error("the F(3x3,3x3) convolution is built for 9x9 boards");
         return GOAI_ERR_ARG;
     }
-    if ((nboards + 3) / 4 <= n_cu) return launch_wino3_9<4>(in, wt_wino3, bias, resid, out, tabs[0], nboards, st);
-    return launch_wino3_9<5>(in, wt_wino3, bias, resid, out, tabs[1], nboards, st);
+    if (n_convs < 1 || (n_convs > 1 && ((n_convs & 1) || resid0))) {
+        set_error("a multi-convolution launch is a whole residual trunk: an even count, no outer residual");
+        return GOAI_ERR_ARG;
+    }
+    if ((nboards + 3) / 4 <= n_cu) return launch_wino3_9<4>(x, y, resid0, wt_wino3, bias, tabs[0], nboards, n_convs, st);
+    return launch_wino3_9<5>(x, y, resid0, wt_wino3, bias, tabs[1], nboards, n_convs, st);
 }
 
 }  // namespace goai

@@ -90,6 +90,7 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
         }
         if (n.wino_mode == 2 && (rc = dev_alloc(c, (void**)&n.wt_wino, (size_t)2 * layers * 16 * 128 * 128 * sizeof(float))))
             return rc;
+        n.trunk_fused = n.wino_mode == 3 && !getenv("GOAI_NO_TRUNK_FUSION");
         if (n.wino_mode == 3) {
             if ((rc = dev_alloc(c, (void**)&n.wt_wino3, (size_t)2 * layers * 25 * 128 * 128 * sizeof(float)))) return rc;
             for (int i = 0; i < 2; i++) {
@@ -316,7 +317,8 @@ static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const f
                                    c->stream);
     const bool wino = net.wino_mode == 2;
     if (net.wino_mode == 3)
-        return launch_conv3x3_wino3(c->S, in, net.wt_wino3 + (size_t)l * 25 * 128 * 128, b, resid, out, net.wino3_tab, M / c->P, net.n_cu, c->stream);
+        return launch_conv3x3_wino3(c->S, const_cast<float*>(in), out, resid, net.wt_wino3 + (size_t)l * 25 * 128 * 128, b,
+                                    net.wino3_tab, M / c->P, net.n_cu, 1, c->stream);
     if (wino)
         return launch_conv3x3_wino(c->S, in, net.wt_wino + (size_t)l * 16 * 128 * 128, b, resid, out, M / c->P, c->stream);
     return launch_conv3x3(c->S, in, net.wt + (size_t)l * 9 * 128 * 128, b, resid, out, M, c->stream);
@@ -349,6 +351,21 @@ int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, in
         if ((rc = launch_conv0(c->S, states + (size_t)done * 6 * P, net.w0, net.w0_split, net.b0, net.shift, net.act[0], nb, c->stream)))
             return rc;
         float *x = net.act[0], *y = net.act[1], *z = net.act[2];
+        if (net.trunk_fused && net.layers > 0) {
+            // F(3x3,3x3): a workgroup owns whole boards, so all 2 * layers convolutions run in one launch
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (c->prof_enabled) {
+                GOAI_HIP_CHECK(hipEventCreate(&e0));
+                GOAI_HIP_CHECK(hipEventCreate(&e1));
+                c->prof_events.push_back(e0);
+                c->prof_events.push_back(e1);
+                GOAI_HIP_CHECK(hipEventRecord(e0, c->stream));
+            }
+            rc = launch_conv3x3_wino3(c->S, x, y, nullptr, net.wt_wino3, net.bt, net.wino3_tab, nb, net.n_cu, 2 * net.layers,
+                                      c->stream);
+            if (e1) GOAI_HIP_CHECK(hipEventRecord(e1, c->stream));
+            if (rc) return rc;
+        } else
         for (int l = 0; l < net.layers; l++) {
             if ((rc = timed_conv(c, x, 2 * l, net.bt + (size_t)(2 * l) * 128, nullptr, y, M))) return rc;
             if ((rc = timed_conv(c, y, 2 * l + 1, net.bt + (size_t)(2 * l + 1) * 128, x, z, M))) return rc;

@@ -39,6 +39,7 @@ _SIGNATURES = {
     "goai_nn_init": [c_void_p, c_int, c_int, c_int, c_int],
     "goai_load_weights": [c_void_p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), c_int],
     "goai_nn_conv_algo": [c_void_p],
+    "goai_nn_convs_per_launch": [c_void_p],
     "goai_nn_forward": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int],
     "goai_mcts_init": [c_void_p, c_int, c_int, c_int],
     "goai_mcts_reset": [c_void_p, c_void_p],

@@ -114,6 +114,13 @@ class Context:
             _hip.check(rc)
         return rc
 
+    def nn_convs_per_launch(self):
+        """Trunk convolutions per kernel launch: 2 * blocks when the F(3x3,3x3) trunk runs as one launch, else 1."""
+        rc = _hip.lib.goai_nn_convs_per_launch(self._h)
+        if rc < 0:
+            _hip.check(rc)
+        return rc
+
     def load_weights(self, state_dict):
         """state_dict: mapping of the reference's keys to float tensors / arrays (host)."""
         names, arrays = [], []

@@ -114,6 +114,12 @@ int goai_nn_init(goai_ctx* ctx, int net_kind, int n_blocks, int max_batch, int d
 #define GOAI_CONV_WINOGRAD_F3 3 /* Winograd F(3x3,3x3), fp32: 9x9 boards */
 int goai_nn_conv_algo(goai_ctx* ctx);
 
+/* How many of the trunk's 3x3 convolutions one kernel launch of this context runs (no reference
+ * counterpart; a measurement aid like goai_nn_conv_algo): 2 * n_blocks when the F(3x3,3x3) kernel,
+ * whose workgroups own whole boards, runs the whole residual trunk in one launch, else 1.
+ * goai_profile_read counts launches. */
+int goai_nn_convs_per_launch(goai_ctx* ctx);
+
 /* Load a state_dict: `names[i]` are the reference's own keys ("main.0.weight",
  * "main.3.main.1.running_var", "act_head.4.bias", "convs.6.weight", ...; what
  * net.state_dict() / torch.load give, /root/reference/go_ai/policies/baselines.py:160-172),

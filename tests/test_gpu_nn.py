@@ -236,3 +236,30 @@ def test_conv_algorithm_is_fixed_per_context(monkeypatch):
     want_pi, want_val = nn_ref.forward(sd, torch.tensor(states), "ac")
     assert rel_err(val.cpu().numpy(), want_val.numpy()) < REL_TOL and rel_err(pi.cpu().numpy(), want_pi.numpy()) < REL_TOL
     c.close()
+
+
+def test_trunk_in_one_launch_equals_one_launch_per_convolution(monkeypatch):
+    """F(3x3,3x3) contexts run the whole residual trunk as ONE launch (a workgroup keeps its boards from
+    layer to layer, odd convolutions add and overwrite the block input in place); with
+    GOAI_NO_TRUNK_FUSION the same kernel is launched once per convolution.  Same arithmetic in the
+    same order: outputs are bit-identical, for 4 and for 5 boards per workgroup, ragged last workgroup
+    included."""
+    from go_ai.engine import Context
+    monkeypatch.setenv("GOAI_CONV_ALGO", "wino3")
+    for n, blocks in [(1024, 3), (1499, 2), (37, 1)]:
+        states = random_positions(9, n, seed=11 + n, canonical=True, pass_prob=0.05)
+        outs = []
+        for fused in (True, False):
+            if fused:
+                monkeypatch.delenv("GOAI_NO_TRUNK_FUSION", raising=False)
+            else:
+                monkeypatch.setenv("GOAI_NO_TRUNK_FUSION", "1")
+            c, sd = make_ctx("ac", 9, 5, blocks, max(n, 1024))
+            assert c.nn_conv_algo() == Context.CONV_WINOGRAD_F3
+            assert c.nn_convs_per_launch() == (2 * blocks if fused else 1)
+            pi, val = c.nn_forward(states, mode=c.NN_RAW)
+            outs.append((pi.cpu().numpy(), val.cpu().numpy()))
+            c.close()
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (n, blocks)
+        want_pi, want_val = nn_ref.forward(sd, torch.tensor(states), "ac")
+        assert rel_err(outs[0][1], want_val.numpy()) < REL_TOL and rel_err(outs[0][0], want_pi.numpy()) < REL_TOL
