@@ -56,6 +56,20 @@ extern "C" int goai_debug_wino3_stamps(unsigned long long* host_out, int n)
 #define W3_STAMP(i)
 #endif
 
+// Diagnostic builds only (tools/wino3_ablate.sh): bit mask of loop parts that are LEFT OUT, to see what
+// each costs.  1: output transform, 2: input transform, 4: A-fragment LDS reads, 8: weight loads,
+// 16: row barrier, 32: the MFMAs.  Any non-zero value computes wrong results.
+#ifndef W3_DIAG
+#define W3_DIAG 0
+#endif
+
+// c * a + b per element as ONE fused operation (the file is compiled with -ffp-contract=off, which would
+// leave the transforms' 2x, 3x and 4x as separate multiplies; vector instructions cost MFMA time here)
+__device__ __forceinline__ f32x4 fma4(float c, f32x4 a, f32x4 b)
+{
+    return f32x4{ fmaf(c, a[0], b[0]), fmaf(c, a[1], b[1]), fmaf(c, a[2], b[2]), fmaf(c, a[3], b[3]) };
+}
+
 __device__ __forceinline__ int w3swz(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
 
 // One launch runs `n_convs` convolutions in a row on the same boards (a workgroup owns whole boards
@@ -146,13 +160,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(float* x, float* y, const
             f32x4 d0[5];
             patch_row(0, d0);
 #pragma unroll
-            for (int b = 0; b < 5; b++) r[b] = 2.0f * d0[b] - d1[b] - 2.0f * d2[b] + d3[b];
+            for (int b = 0; b < 5; b++) r[b] = fma4(-2.0f, d2[b], fma4(2.0f, d0[b], d3[b] - d1[b]));
         } else if (p == 1) {
 #pragma unroll
-            for (int b = 0; b < 5; b++) r[b] = d3[b] - 2.0f * d1[b] - d2[b];
+            for (int b = 0; b < 5; b++) r[b] = fma4(-2.0f, d1[b], d3[b] - d2[b]);
         } else if (p == 2) {
 #pragma unroll
-            for (int b = 0; b < 5; b++) r[b] = 2.0f * d1[b] - 3.0f * d2[b] + d3[b];
+            for (int b = 0; b < 5; b++) r[b] = fma4(-3.0f, d2[b], fma4(2.0f, d1[b], d3[b]));
         } else if (p == 3) {
 #pragma unroll
             for (int b = 0; b < 5; b++) r[b] = d3[b] - d1[b];
@@ -160,14 +174,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(float* x, float* y, const
             f32x4 d4[5];
             patch_row(4, d4);
 #pragma unroll
-            for (int b = 0; b < 5; b++) r[b] = 2.0f * d1[b] - d2[b] - 2.0f * d3[b] + d4[b];
+            for (int b = 0; b < 5; b++) r[b] = fma4(-2.0f, d3[b], fma4(2.0f, d1[b], d4[b] - d2[b]));
         }
         f32x4* V = Vs + vbuf * W::V_U4;
-        V[w3swz(0 * ROWS + ttw, ts)] = 2.0f * r[0] - r[1] - 2.0f * r[2] + r[3];
-        V[w3swz(1 * ROWS + ttw, ts)] = r[3] - 2.0f * r[1] - r[2];
-        V[w3swz(2 * ROWS + ttw, ts)] = 2.0f * r[1] - 3.0f * r[2] + r[3];
+        V[w3swz(0 * ROWS + ttw, ts)] = fma4(-2.0f, r[2], fma4(2.0f, r[0], r[3] - r[1]));
+        V[w3swz(1 * ROWS + ttw, ts)] = fma4(-2.0f, r[1], r[3] - r[2]);
+        V[w3swz(2 * ROWS + ttw, ts)] = fma4(-3.0f, r[2], fma4(2.0f, r[1], r[3]));
         V[w3swz(3 * ROWS + ttw, ts)] = r[3] - r[1];
-        V[w3swz(4 * ROWS + ttw, ts)] = 2.0f * r[1] - r[2] - 2.0f * r[3] + r[4];
+        V[w3swz(4 * ROWS + ttw, ts)] = fma4(-2.0f, r[3], fma4(2.0f, r[1], r[4] - r[2]));
     };
 
     // weight fragments of a stage: U[stage][cout = 16 wave + li][32 in], k = kk*16 + lq*4 + jj
@@ -204,6 +218,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(float* x, float* y, const
     __syncthreads();
 
     W3_STAMP(1);
+    f32x4 afix[MT];
+    if (W3_DIAG & 4) {
+#pragma unroll
+        for (int t = 0; t < MT; t++) afix[t] = Vs[w3swz(t * 16 + li, lq)];
+    }
+    if (W3_DIAG & 8) { bnxt[0] = bcur[0]; bnxt[1] = bcur[1]; }
 #pragma unroll 1
     for (int chunk = 0; chunk < 4; chunk++) {
         if (chunk == 1) { W3_STAMP(2); }
@@ -220,9 +240,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(float* x, float* y, const
             const f32x4* V = Vs + (rowi & 1) * W::V_U4;
 #pragma unroll 1
             for (int q = 0; q < 5; q++) {
-                if (more && q == tq) transform(p == 4 ? 0 : p + 1, (rowi + 1) & 1);
+                if (more && q == tq && !(W3_DIAG & 2)) transform(p == 4 ? 0 : p + 1, (rowi + 1) & 1);
                 const int s = rowi * 5 + q;
-                if (s + 1 < 100) load_b(s + 1, bnxt);
+                if (s + 1 < 100 && !(W3_DIAG & 8)) load_b(s + 1, bnxt);
 
                 f32x4 m[MT];
 #pragma unroll
@@ -231,12 +251,24 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(float* x, float* y, const
                 for (int kk = 0; kk < 2; kk++) {
                     f32x4 a[MT];
 #pragma unroll
-                    for (int t = 0; t < MT; t++) a[t] = V[w3swz(q * ROWS + t * 16 + li, kk * 4 + lq)];
+                    for (int t = 0; t < MT; t++) a[t] = (W3_DIAG & 4) ? afix[t] : V[w3swz(q * ROWS + t * 16 + li, kk * 4 + lq)];
+                    if (W3_DIAG & 32) {
+#pragma unroll
+                        for (int t = 0; t < MT; t++) m[t] += a[t] * bcur[kk];
+                        continue;
+                    }
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++)
 #pragma unroll
                         for (int t = 0; t < MT; t++)
                             m[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[kk][jj], a[t][jj], m[t], 0, 0, 0);
+                }
+                if (W3_DIAG & 1) {
+#pragma unroll
+                    for (int t = 0; t < MT; t++) Y[0][0][t] += m[t];
+                    bcur[0] = bnxt[0];
+                    bcur[1] = bnxt[1];
+                    continue;
                 }
                 // output transform: Y[i][j] += At[i][p] * At[j][q] * M; p is unrolled (row factors at
                 // compile time, zeros skipped), q is a run-time loop (column factors as floats)
@@ -263,7 +295,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(float* x, float* y, const
                 bcur[0] = bnxt[0];
                 bcur[1] = bnxt[1];
             }
-            __syncthreads();
+            if (!(W3_DIAG & 16)) __syncthreads();
         }
     }
 
