@@ -29,6 +29,8 @@ struct Net {
     float* wt = nullptr;       // f32:  [2*layers][4 chunks][9 taps][128 out][32 in]
     float* wt_wino = nullptr;  // f32 Winograd F(2x2,3x3): [2*layers][4 chunks][16 xi][128 out][32 in] = G g Gt (null: direct only)
     int wino_mode = 0;         // 0: direct kernel, 2: Winograd F(2x2,3x3), 3: Winograd F(3x3,3x3) (chosen in nn_init)
+    bool wino3_paired = false; // F(3x3,3x3) with two chunks per output transform (conv_wino3p_kernels.hip): max_batch <= 4 * CUs
+    void* wino3p_tab = nullptr;
     bool trunk_fused = false;  // F(3x3,3x3) only: all 2 * layers convolutions of a forward in one launch
     float* wt_wino3 = nullptr; // F(3x3,3x3): [2*layers][4 chunks][25 xi][128 out][32 in]
     void* wino3_tab[2] = { nullptr, nullptr };   // input-transform address tables for 4 / 5 boards per workgroup
@@ -54,6 +56,10 @@ size_t wino3_build_table(int S, int nbw, uint16_t* out);
 // residual trunk in one launch (weights / biases of consecutive layers contiguous), result in x
 int launch_conv3x3_wino3(int S, float* x, float* y, const float* resid0, const float* wt_wino3, const float* bias,
                          const void* const* tabs, int nboards, int n_cu, int n_convs, hipStream_t st);
+int wino3p_supported(int S, int max_batch, int n_cu);
+size_t wino3p_build_table(int S, uint16_t* out);
+int launch_conv3x3_wino3p(int S, float* x, float* y, const float* resid0, const float* wt_wino3, const float* bias,
+                          const void* tab, int nboards, int n_cu, int n_convs, hipStream_t st);
 int launch_conv3x3_wino(int S, const float* in, const float* wt_wino, const float* bias, const float* resid, float* out,
                         int nboards, hipStream_t st);
 int launch_heads(int S, const float* act, const HeadWeights& hw, int is_ac, float* pi, float* val, int nboards,

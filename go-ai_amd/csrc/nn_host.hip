@@ -91,6 +91,16 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
         if (n.wino_mode == 2 && (rc = dev_alloc(c, (void**)&n.wt_wino, (size_t)2 * layers * 16 * 128 * 128 * sizeof(float))))
             return rc;
         n.trunk_fused = n.wino_mode == 3 && !getenv("GOAI_NO_TRUNK_FUSION");
+        {
+            const char* e = getenv("GOAI_WINO3_PAIRED");
+            n.wino3_paired = n.wino_mode == 3 && wino3p_supported(c->S, max_batch, n.n_cu) && !(e && e[0] == '0');
+        }
+        if (n.wino3_paired) {
+            std::vector<uint16_t> tab(wino3p_build_table(c->S, nullptr));
+            wino3p_build_table(c->S, tab.data());
+            if ((rc = dev_alloc(c, &n.wino3p_tab, tab.size() * sizeof(uint16_t)))) return rc;
+            GOAI_HIP_CHECK(hipMemcpy(n.wino3p_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
         if (n.wino_mode == 3) {
             if ((rc = dev_alloc(c, (void**)&n.wt_wino3, (size_t)2 * layers * 25 * 128 * 128 * sizeof(float)))) return rc;
             for (int i = 0; i < 2; i++) {
@@ -316,6 +326,9 @@ static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const f
         return launch_conv3x3_bf16(c->S, in, (const uint16_t*)net.wt_bf16 + (size_t)l * WT_BF16_PER_CONV, b, resid, out, M,
                                    c->stream);
     const bool wino = net.wino_mode == 2;
+    if (net.wino3_paired)
+        return launch_conv3x3_wino3p(c->S, const_cast<float*>(in), out, resid, net.wt_wino3 + (size_t)l * 25 * 128 * 128, b,
+                                     net.wino3p_tab, M / c->P, net.n_cu, 1, c->stream);
     if (net.wino_mode == 3)
         return launch_conv3x3_wino3(c->S, const_cast<float*>(in), out, resid, net.wt_wino3 + (size_t)l * 25 * 128 * 128, b,
                                     net.wino3_tab, M / c->P, net.n_cu, 1, c->stream);
@@ -361,8 +374,11 @@ int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, in
                 c->prof_events.push_back(e1);
                 GOAI_HIP_CHECK(hipEventRecord(e0, c->stream));
             }
-            rc = launch_conv3x3_wino3(c->S, x, y, nullptr, net.wt_wino3, net.bt, net.wino3_tab, nb, net.n_cu, 2 * net.layers,
-                                      c->stream);
+            rc = net.wino3_paired
+                     ? launch_conv3x3_wino3p(c->S, x, y, nullptr, net.wt_wino3, net.bt, net.wino3p_tab, nb, net.n_cu,
+                                             2 * net.layers, c->stream)
+                     : launch_conv3x3_wino3(c->S, x, y, nullptr, net.wt_wino3, net.bt, net.wino3_tab, nb, net.n_cu,
+                                            2 * net.layers, c->stream);
             if (e1) GOAI_HIP_CHECK(hipEventRecord(e1, c->stream));
             if (rc) return rc;
         } else
