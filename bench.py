@@ -171,7 +171,7 @@ def main():
     achieved = conv_flop / (conv_ms / conv_n * 1e-3) / 1e12
     peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS / 3.0
     algo = sp.ctx.nn_conv_algo()
-    kname = {0: "k_conv3x3", 1: "k_conv3x3_wino", 2: "k_conv3x3_bf16", 3: "k_conv3x3_wino3"}[algo] + f"<{SIZE}>"
+    kname = {0: "k_conv3x3", 1: "k_conv3x3_wino", 2: "k_conv3x3_bf16", 3: "k_conv3x3_wino3", 4: "k_conv3x3_wino3p"}[algo] + f"<{SIZE}>"
     executed_flop = conv_flop
     if algo == 1:
         # Winograd F(2x2,3x3): 16 products per 2x2 output tile and (cin, cout) instead of 36, on
@@ -179,7 +179,7 @@ def main():
         t2 = ((SIZE + 1) // 2) ** 2
         wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // (112 // t2))
         executed_flop = 2.0 * wgs * 112 * 16 * 128 * 128
-    elif algo == 3:
+    elif algo in (3, 4):
         # Winograd F(3x3,3x3): 25 products per 3x3 output tile; workgroups of 48 tile rows = 4 boards of 9x9
         # (5 boards once 4 per workgroup would need more than one round of CUs)
         nb = int(round(conv_rows / (SIZE * SIZE)))
@@ -220,7 +220,8 @@ def main():
                          "flop_per_launch": conv_flop, "convs_per_launch": cpl,
                          "algorithm": {0: "direct implicit GEMM, fp32 MFMA", 1: "Winograd F(2x2,3x3), fp32 MFMA",
                                        2: "direct implicit GEMM, bf16 MFMA on hi+lo split operands",
-                                       3: "Winograd F(3x3,3x3), fp32 MFMA"}[algo],
+                                       3: "Winograd F(3x3,3x3), fp32 MFMA",
+                                       4: "Winograd F(3x3,3x3), fp32 MFMA, two 32-channel chunks per output transform"}[algo],
                          "executed_mfma_flop_per_launch": executed_flop,
                          "mfma_pipe_frac": round(executed_flop / (conv_ms / conv_n * 1e-3) / 1e12 / peak, 4)},
             "games": {"total": int(tot["games"]), "finished": int(tot["finished"]),

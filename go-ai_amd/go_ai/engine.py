@@ -105,7 +105,7 @@ class Context:
         self.net_kind = int(net_kind)
         _hip.check(_hip.lib.goai_nn_init(self._h, self.net_kind, int(n_blocks), int(max_batch), int(dtype)))
 
-    CONV_DIRECT, CONV_WINOGRAD, CONV_BF16X3, CONV_WINOGRAD_F3 = 0, 1, 2, 3
+    CONV_DIRECT, CONV_WINOGRAD, CONV_BF16X3, CONV_WINOGRAD_F3, CONV_WINOGRAD_F3_PAIRED = 0, 1, 2, 3, 4
 
     def nn_conv_algo(self):
         """The 3x3 convolution kernel nn_init chose for this context (CONV_*)."""

@@ -104,7 +104,7 @@ int goai_nn_init(goai_ctx* ctx, int net_kind, int n_blocks, int max_batch, int d
 
 /* Which kernel goai_nn_init chose for the trunk's 3x3 convolutions of this context (no reference
  * counterpart: the reference leaves the choice to torch / MKL-DNN).  GOAI_DTYPE_F32 contexts run
- * Winograd in fp32 (F(3x3,3x3) on 9x9, F(2x2,3x3) on larger boards) when max_batch fills the chip
+ * Winograd in fp32 (F(3x3,3x3) on 9x9 -- its _PAIRED form when max_batch is at most 4 boards per CU --, F(2x2,3x3) on larger boards) when max_batch fills the chip
  * with its workgroups, else the direct implicit GEMM; the choice is fixed per context so that a
  * position's output never depends on the size of the batch it is evaluated in.  Returns one of
  * the GOAI_CONV_* values, or a negative error code. */
@@ -112,6 +112,7 @@ int goai_nn_init(goai_ctx* ctx, int net_kind, int n_blocks, int max_batch, int d
 #define GOAI_CONV_WINOGRAD 1
 #define GOAI_CONV_BF16X3 2
 #define GOAI_CONV_WINOGRAD_F3 3 /* Winograd F(3x3,3x3), fp32: 9x9 boards */
+#define GOAI_CONV_WINOGRAD_F3_PAIRED 4 /* the same with two 32-channel chunks per output transform: 9x9, max_batch <= 4 boards per CU */
 int goai_nn_conv_algo(goai_ctx* ctx);
 
 /* How many of the trunk's 3x3 convolutions one kernel launch of this context runs (no reference

@@ -50,7 +50,7 @@ def full():
 def test_full_config_search_invariants(full):
     from go_ai.engine import Context
     roots, (visits, prior, root_visits, pi, acts, cnt, algo) = full
-    assert algo == Context.CONV_WINOGRAD_F3       # 1024 boards of 9x9 fill the chip: the bench's kernel
+    assert algo == Context.CONV_WINOGRAD_F3_PAIRED    # 1024 boards of 9x9 = 4 per CU: the bench's kernel
     assert cnt["errors"] == 0 and cnt["leaf_evals"] == GAMES * (SIMS + 1)
     st = roots.cpu().numpy()
     valid = np.concatenate([1 - st[:, 3].reshape(GAMES, -1), np.ones((GAMES, 1), np.uint8)], axis=1).astype(bool)

@@ -217,7 +217,7 @@ def test_conv_algorithm_is_fixed_per_context(monkeypatch):
     the chip, boards >= 9x9), so a position's output does not depend on its batch."""
     from go_ai.engine import Context
     monkeypatch.delenv("GOAI_CONV_ALGO", raising=False)
-    for size, max_batch, want in [(9, 1024, Context.CONV_WINOGRAD_F3), (9, 64, Context.CONV_DIRECT), (13, 512, Context.CONV_WINOGRAD),
+    for size, max_batch, want in [(9, 1024, Context.CONV_WINOGRAD_F3_PAIRED), (9, 4096, Context.CONV_WINOGRAD_F3), (9, 64, Context.CONV_DIRECT), (13, 512, Context.CONV_WINOGRAD),
                                   (5, 4096, Context.CONV_DIRECT), (19, 512, Context.CONV_WINOGRAD)]:
         c = Context(size)
         c.nn_init(Context.NET_AC, 3, max_batch)
@@ -228,7 +228,7 @@ def test_conv_algorithm_is_fixed_per_context(monkeypatch):
     assert c.nn_conv_algo() == Context.CONV_BF16X3
     c.close()
     c, sd = make_ctx("ac", 9, 5, 3, 1024)
-    assert c.nn_conv_algo() == Context.CONV_WINOGRAD_F3
+    assert c.nn_conv_algo() == Context.CONV_WINOGRAD_F3_PAIRED
     states = random_positions(9, 300, seed=3, canonical=True, pass_prob=0.05)
     pi, val = c.nn_forward(states, mode=c.NN_RAW)
     pi1, val1 = c.nn_forward(states[7:8], mode=c.NN_RAW)
@@ -255,7 +255,7 @@ def test_trunk_in_one_launch_equals_one_launch_per_convolution(monkeypatch):
             else:
                 monkeypatch.setenv("GOAI_NO_TRUNK_FUSION", "1")
             c, sd = make_ctx("ac", 9, 5, blocks, max(n, 1024))
-            assert c.nn_conv_algo() == Context.CONV_WINOGRAD_F3
+            assert c.nn_conv_algo() == (Context.CONV_WINOGRAD_F3_PAIRED if n <= 1024 else Context.CONV_WINOGRAD_F3)
             assert c.nn_convs_per_launch() == (2 * blocks if fused else 1)
             pi, val = c.nn_forward(states, mode=c.NN_RAW)
             outs.append((pi.cpu().numpy(), val.cpu().numpy()))
@@ -263,3 +263,27 @@ def test_trunk_in_one_launch_equals_one_launch_per_convolution(monkeypatch):
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (n, blocks)
         want_pi, want_val = nn_ref.forward(sd, torch.tensor(states), "ac")
         assert rel_err(outs[0][1], want_val.numpy()) < REL_TOL and rel_err(outs[0][0], want_pi.numpy()) < REL_TOL
+
+
+def test_f3_paired_and_unpaired_kernels_agree_within_fp32_rounding(monkeypatch):
+    """A 9x9 context of at most 4 boards per CU runs F(3x3,3x3) with two 32-channel chunks per output
+    transform (conv_wino3p_kernels.hip); GOAI_WINO3_PAIRED=0 keeps the one-chunk kernel.  Different
+    summation order, same bound against the torch oracle, and ~1e-6 from each other."""
+    from go_ai.engine import Context
+    monkeypatch.setenv("GOAI_CONV_ALGO", "wino3")
+    states = random_positions(9, 700, seed=5, canonical=True, pass_prob=0.05)
+    outs = {}
+    for paired in (True, False):
+        if paired:
+            monkeypatch.delenv("GOAI_WINO3_PAIRED", raising=False)
+        else:
+            monkeypatch.setenv("GOAI_WINO3_PAIRED", "0")
+        c, sd = make_ctx("ac", 9, 21, 3, 1024)
+        assert c.nn_conv_algo() == (Context.CONV_WINOGRAD_F3_PAIRED if paired else Context.CONV_WINOGRAD_F3)
+        pi, val = c.nn_forward(states, mode=c.NN_RAW)
+        outs[paired] = (pi.cpu().numpy(), val.cpu().numpy())
+        c.close()
+    want_pi, want_val = nn_ref.forward(sd, torch.tensor(states), "ac")
+    for paired in (True, False):
+        assert rel_err(outs[paired][1], want_val.numpy()) < REL_TOL and rel_err(outs[paired][0], want_pi.numpy()) < REL_TOL
+    assert rel_err(outs[True][0], outs[False][0]) < 1e-4 and rel_err(outs[True][1], outs[False][1]) < 1e-4
