@@ -26,7 +26,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int S>
 struct Wino3P {
-    static_assert(S % 3 == 0, "F(3x3,3x3) tiles must cover the board exactly");
+    static_assert(S == 9, "row mapping: 8 + 1 wtiles per board, 4 boards");
     static constexpr int T = S / 3, T2 = T * T, P = S * S;
     static constexpr int NBW = 4;                                  // whole boards per workgroup
     static constexpr int WT = NBW * T2;                            // real wtiles per workgroup
@@ -78,6 +78,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3p(float* x, float* y, cons
     const int item = (tid >> 4) * LPG + (tid & 15);
     const bool t_on = (tid & 15) < LPG && item < W::WT * 8;
     const int ts = item & 7, ttw = t_on ? item >> 3 : 0;
+    // MFMA row of a wtile: wtiles 0..7 of board b -> row 8 b + wtile (two 16-row tiles, v_mfma_f32_16x16x4_f32);
+    // wtile 8 of board b -> row 32 + b (v_mfma_f32_4x4x1_16b_f32, below).  Every board is treated alike.
+    const int tvrow = (ttw % W::T2 < 8) ? (ttw / W::T2) * 8 + ttw % W::T2 : 32 + ttw / W::T2;
 
     f32x4 ireg[W::NI];
     auto load_img_to = [&](int chunk, f32x4* reg) {
@@ -140,11 +143,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3p(float* x, float* y, cons
             for (int b = 0; b < 5; b++) r[b] = p_fma4(-2.0f, d3[b], p_fma4(2.0f, d1[b], d4[b] - d2[b]));
         }
         f32x4* V = Vs + c * W::V_CH_U4;
-        V[p_swz(0 * ROWS + ttw, ts)] = p_fma4(-2.0f, r[2], p_fma4(2.0f, r[0], r[3] - r[1]));
-        V[p_swz(1 * ROWS + ttw, ts)] = p_fma4(-2.0f, r[1], r[3] - r[2]);
-        V[p_swz(2 * ROWS + ttw, ts)] = p_fma4(-3.0f, r[2], p_fma4(2.0f, r[1], r[3]));
-        V[p_swz(3 * ROWS + ttw, ts)] = r[3] - r[1];
-        V[p_swz(4 * ROWS + ttw, ts)] = p_fma4(-2.0f, r[3], p_fma4(2.0f, r[1], r[4] - r[2]));
+        V[p_swz(0 * ROWS + tvrow, ts)] = p_fma4(-2.0f, r[2], p_fma4(2.0f, r[0], r[3] - r[1]));
+        V[p_swz(1 * ROWS + tvrow, ts)] = p_fma4(-2.0f, r[1], r[3] - r[2]);
+        V[p_swz(2 * ROWS + tvrow, ts)] = p_fma4(-3.0f, r[2], p_fma4(2.0f, r[1], r[3]));
+        V[p_swz(3 * ROWS + tvrow, ts)] = r[3] - r[1];
+        V[p_swz(4 * ROWS + tvrow, ts)] = p_fma4(-2.0f, r[3], p_fma4(2.0f, r[1], r[4] - r[2]));
     };
 
     // weight fragments of a half-stage: U[stage = (chunk * 5 + p) * 5 + q][cout = 16 wave + li][32 in]
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3p(float* x, float* y, cons
                 f32x4 m[MT];
 #pragma unroll
                 for (int t = 0; t < MT; t++) m[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+                f32x4 m2b = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
                     // the next half-stage's weights: (q, c = 1), else (q + 1, 0), else the next row / chunk pair
@@ -213,16 +217,26 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3p(float* x, float* y, cons
                     for (int kk = 0; kk < 2; kk++) {
                         f32x4 a[MT];
 #pragma unroll
-                        for (int t = 0; t < MT; t++) a[t] = V[p_swz(q * ROWS + t * 16 + li, kk * 4 + lq)];
+                        for (int t = 0; t < 2; t++) a[t] = V[p_swz(q * ROWS + t * 16 + li, kk * 4 + lq)];
+                        a[2] = V[p_swz(q * ROWS + 32 + (li & 3), kk * 4 + lq)];
 #pragma unroll
-                        for (int jj = 0; jj < 4; jj++)
+                        for (int jj = 0; jj < 4; jj++) {
 #pragma unroll
-                            for (int t = 0; t < MT; t++)
+                            for (int t = 0; t < 2; t++)
                                 m[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[kk][jj], a[t][jj], m[t], 0, 0, 0);
+                            // rows 32..35 (4 wtiles x this wave's 16 output channels): sixteen 4x4 blocks,
+                            // block = lane / 4 = (k slice lq, channel group li / 4); the lane's weight register
+                            // IS the block's A element (channel li, k = 16 kk + 4 lq + jj), B = V[32 + li % 4].
+                            // m[2] = partial sums over this lane's k slice; the four slices meet in the epilogue.
+                            // (two accumulators, even / odd jj: back-to-back dependent 4x4 MFMAs would need wait states)
+                            if (jj & 1) m2b = __builtin_amdgcn_mfma_f32_4x4x1f32(bcur[kk][jj], a[2][jj], m2b, 0, 0, 0);
+                            else m[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(bcur[kk][jj], a[2][jj], m[2], 0, 0, 0);
+                        }
                     }
                     bcur[0] = bnxt[0];
                     bcur[1] = bnxt[1];
                 }
+                m[2] += m2b;
                 // output transform: Y[i][j] += At[i][p] * At[j][q] * M; p is unrolled (row factors at
                 // compile time, zeros skipped), q is a run-time loop (column factors as floats)
                 const float cj0 = (q < 4) ? 1.0f : 0.0f;
@@ -256,25 +270,48 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3p(float* x, float* y, cons
 
     // epilogue.  The products are formed transposed (A operand = weights, B operand = V), so in the
     // C/D layout of a 16x16 tile (col = lane & 15, row = 4 * (lane >> 4) + reg) a lane holds FOUR
-    // CONSECUTIVE output channels of ONE wtile: one 16-byte load / store per output cell.
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col]);
+    // CONSECUTIVE output channels of ONE wtile: one 16-byte load / store per output cell.  In the 4x4
+    // blocks a lane holds channels 4 (li / 4) .. + 3 of wtile row 32 + li % 4 for its k slice: the four
+    // slices (lanes l, l ^ 16, l ^ 32, l ^ 48) are summed in a fixed order, lanes 0..15 store.
+    auto finish = [&](const f32x4 yv, const f32x4 bv, long off) {
+        f32x4 v = yv + bv;
+        if (resid) v += *reinterpret_cast<const f32x4*>(&resid[off]);
 #pragma unroll
-    for (int t = 0; t < MT; t++) {
-        const int w = t * 16 + li;
-        const int bl = w / W::T2, rem = w - bl * W::T2;
-        const long board = b_first + bl;
-        if (w >= W::WT || board >= nboards) continue;
-        const int ty = rem / W::T, tx = rem - ty * W::T;
+        for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
+        *reinterpret_cast<f32x4*>(&out[off]) = v;
+    };
+    {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col]);
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int w = t * 16 + li;
+            const int bl = w >> 3, wt = w & 7;
+            const long board = b_first + bl;
+            if (board >= nboards) continue;
+            const int ty = wt / W::T, tx = wt - ty * W::T;
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    finish(Y[i][j][t], bv, (board * P + (3 * ty + i) * S + 3 * tx + j) * 128 + col);
+        }
+    }
+    {
+        const int col2 = wave * 16 + (li & 12);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col2]);
+        const long board = b_first + (li & 3);
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                const long off = (board * P + (3 * ty + i) * S + 3 * tx + j) * 128 + col;
-                f32x4 v = Y[i][j][t] + bv;
-                if (resid) v += *reinterpret_cast<const f32x4*>(&resid[off]);
+                f32x4 v = Y[i][j][2];
 #pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
-                *reinterpret_cast<f32x4*>(&out[off]) = v;
+                for (int e = 0; e < 4; e++) {
+                    v[e] += __shfl_xor(v[e], 16);
+                    v[e] += __shfl_xor(v[e], 32);
+                }
+                if (lq == 0 && board < nboards)          // wtile 8 = (ty, tx) = (2, 2)
+                    finish(v, bv, (board * P + (6 + i) * S + 6 + j) * 128 + col2);
             }
     }
     // next convolution of the launch: swap the buffers, step the weights
