@@ -185,7 +185,8 @@ def main():
         nb = int(round(conv_rows / (SIZE * SIZE)))
         n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
         wgs = -(-nb // 4) if -(-nb // 4) <= n_cu else -(-nb // 5)
-        executed_flop = 2.0 * wgs * 48 * 25 * 128 * 128 * cpl
+        # (the two-chunk kernel runs 32 rows as 16x16x4 tiles and the other 4 as 4x4x1 blocks: no padded rows)
+        executed_flop = 2.0 * wgs * (36 if algo == 4 else 48) * 25 * 128 * 128 * cpl
 
     # the one collective of the run: gather per-rank results (utils.py:201-204's allreduces)
     from go_ai.sharding import gather_stats, reduce_stats
@@ -221,7 +222,7 @@ def main():
                          "algorithm": {0: "direct implicit GEMM, fp32 MFMA", 1: "Winograd F(2x2,3x3), fp32 MFMA",
                                        2: "direct implicit GEMM, bf16 MFMA on hi+lo split operands",
                                        3: "Winograd F(3x3,3x3), fp32 MFMA",
-                                       4: "Winograd F(3x3,3x3), fp32 MFMA, two 32-channel chunks per output transform"}[algo],
+                                       4: "Winograd F(3x3,3x3), fp32 MFMA (16x16x4 + 4x4x1), two 32-channel chunks per output transform"}[algo],
                          "executed_mfma_flop_per_launch": executed_flop,
                          "mfma_pipe_frac": round(executed_flop / (conv_ms / conv_n * 1e-3) / 1e12 / peak, 4)},
             "games": {"total": int(tot["games"]), "finished": int(tot["finished"]),
