@@ -287,3 +287,24 @@ def test_f3_paired_and_unpaired_kernels_agree_within_fp32_rounding(monkeypatch):
     for paired in (True, False):
         assert rel_err(outs[paired][1], want_val.numpy()) < REL_TOL and rel_err(outs[paired][0], want_pi.numpy()) < REL_TOL
     assert rel_err(outs[True][0], outs[False][0]) < 1e-4 and rel_err(outs[True][1], outs[False][1]) < 1e-4
+
+
+def test_f3_paired_output_does_not_depend_on_position_in_batch():
+    """conv_wino3p_kernels.hip sends the ninth tile of every board through 4x4 MFMA blocks and the other
+    eight through 16x16 tiles -- every board alike, so the same state gives the same bits wherever it
+    sits in a workgroup (4 boards) or in the batch, and whatever shares the batch with it."""
+    c, sd = make_ctx("ac", 9, 31, 3, 1024)
+    from go_ai.engine import Context
+    assert c.nn_conv_algo() == Context.CONV_WINOGRAD_F3_PAIRED
+    states = random_positions(9, 203, seed=77, canonical=True, pass_prob=0.05)
+    probe = states[11]
+    batch = states.copy()
+    where = [0, 1, 2, 3, 6, 101, 202]
+    for w in where:
+        batch[w] = probe
+    pi, val = c.nn_forward(batch, mode=c.NN_RAW)
+    pi, val = pi.cpu().numpy(), val.cpu().numpy()
+    pi1, val1 = c.nn_forward(probe[None], mode=c.NN_RAW)
+    for w in where + [11]:
+        assert np.array_equal(pi[w], pi1.cpu().numpy()[0]) and np.array_equal(val[w], val1.cpu().numpy()[0]), w
+    c.close()
