@@ -178,7 +178,8 @@ def main():
         # workgroups of 112 tile rows holding NBW whole boards (conv_wino_kernels.hip)
         t2 = ((SIZE + 1) // 2) ** 2
         wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // (112 // t2))
-        executed_flop = 2.0 * wgs * 112 * 16 * 128 * 128
+        rows = 100 if SIZE in (9, 13, 19) else 112       # six 16-row tiles + one round of 4x4 blocks, or seven tiles
+        executed_flop = 2.0 * wgs * rows * 16 * 128 * 128
     elif algo in (3, 4):
         # Winograd F(3x3,3x3): 25 products per 3x3 output tile; workgroups of 48 tile rows = 4 boards of 9x9
         # (5 boards once 4 per workgroup would need more than one round of CUs)

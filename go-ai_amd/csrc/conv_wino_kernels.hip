@@ -51,6 +51,13 @@ struct Wino {
     static constexpr int SLACK_U4 = (ROWS - VP) * 8;               // rows WT..ROWS-1 of the last q read past it
     static constexpr int TAB_U4 = WT * 2;                          // 16 x u16 LDS addresses per wtile
     static constexpr int NI = (NBW * P * 8 + 511) / 512;           // staged 16-byte pieces per thread per chunk
+    // 9x9 (100 wtiles), 13x13 (98) and 19x19 (100) are six full 16-row MFMA tiles plus 4 / 2 / 4 wtiles:
+    // that tail runs on v_mfma_f32_4x4x1_16b_f32 blocks (see the loop) instead of a seventh, three-quarters
+    // empty tile.  The tail holds the LAST TPB wtiles of every board, so all boards are treated alike:
+    // MFMA row of (board b, wtile w) = w < MAIN ? b * MAIN + w : 96 + b * TPB + (w - MAIN).
+    static constexpr int TAIL = WT - 96;
+    static constexpr bool USE4 = TAIL > 0 && TAIL <= 4 && TAIL % NBW == 0;
+    static constexpr int TPB = USE4 ? TAIL / NBW : 0, MAIN = T2 - TPB;
     static constexpr int LDS_U4 = IMG_U4 + 2 * V_U4 + SLACK_U4 + TAB_U4;
     static_assert(NBW >= 1, "board too large for one workgroup");
     static_assert(LDS_U4 * 16 <= 160 * 1024, "LDS budget");
@@ -141,6 +148,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
         for (int j = 0; j < 2; j++) {
             const int tw = (tid >> 3) + 64 * j;
             if (tw >= W::WT) continue;
+            int vr = tw;                             // MFMA row of this wtile
+            if constexpr (W::USE4) {
+                const int bl = tw / W::T2, wt_ = tw - bl * W::T2;
+                vr = wt_ < W::MAIN ? bl * W::MAIN + wt_ : 96 + bl * W::TPB + (wt_ - W::MAIN);
+            }
             const uint2 t1 = *reinterpret_cast<const uint2*>(&Tab[tw * 16 + a1 * 4]);
             const uint2 t2 = *reinterpret_cast<const uint2*>(&Tab[tw * 16 + a2 * 4]);
             f32x4 r[4];
@@ -148,10 +160,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
             r[1] = s1 * img_at(t1.x >> 16) + s2 * img_at(t2.x >> 16);
             r[2] = s1 * img_at(t1.y & 0xffffu) + s2 * img_at(t2.y & 0xffffu);
             r[3] = s1 * img_at(t1.y >> 16) + s2 * img_at(t2.y >> 16);
-            V[wswz(0 * W::VP + tw, ts)] = r[0] - r[2];
-            V[wswz(1 * W::VP + tw, ts)] = r[1] + r[2];
-            V[wswz(2 * W::VP + tw, ts)] = r[2] - r[1];
-            V[wswz(3 * W::VP + tw, ts)] = r[1] - r[3];
+            V[wswz(0 * W::VP + vr, ts)] = r[0] - r[2];
+            V[wswz(1 * W::VP + vr, ts)] = r[1] + r[2];
+            V[wswz(2 * W::VP + vr, ts)] = r[2] - r[1];
+            V[wswz(3 * W::VP + vr, ts)] = r[1] - r[3];
         }
     };
 
@@ -207,17 +219,31 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
                 f32x4 m[MT];
 #pragma unroll
                 for (int t = 0; t < MT; t++) m[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+                f32x4 m6b = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
                 for (int kk = 0; kk < 2; kk++) {
                     f32x4 a[MT];
 #pragma unroll
-                    for (int t = 0; t < MT; t++) a[t] = V[wswz(q * W::VP + t * 16 + li, kk * 4 + lq)];
+                    for (int t = 0; t < MT; t++)
+                        a[t] = V[wswz(q * W::VP + ((W::USE4 && t == 6) ? 96 + (li & 3) : t * 16 + li), kk * 4 + lq)];
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++)
 #pragma unroll
-                        for (int t = 0; t < MT; t++)
-                            m[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[kk][jj], a[t][jj], m[t], 0, 0, 0);
+                        for (int t = 0; t < MT; t++) {
+                            if (W::USE4 && t == 6) {
+                                // rows 96..99: sixteen 4x4 blocks, block = lane / 4 = (k slice lq, channel group
+                                // li / 4); the lane's weight register IS the block's A element (channel li,
+                                // k = 16 kk + 4 lq + jj), B = V[96 + li % 4].  Partial sums over the lane's k slice
+                                // (two accumulators: dependent 4x4 MFMAs need wait states); the output transform
+                                // is linear, the four slices meet in the epilogue.
+                                if (jj & 1) m6b = __builtin_amdgcn_mfma_f32_4x4x1f32(bcur[kk][jj], a[t][jj], m6b, 0, 0, 0);
+                                else m[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(bcur[kk][jj], a[t][jj], m[t], 0, 0, 0);
+                            } else {
+                                m[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[kk][jj], a[t][jj], m[t], 0, 0, 0);
+                            }
+                        }
                 }
+                if (W::USE4) m[6] += m6b;
                 // output transform: Y[i][j] += At[i][p] * At[j][q] * M,  At = (1 1 1 0 ; 0 1 -1 -1);
                 // p is unrolled (compile-time row factor), q is a run-time loop (column factor as +-1.0 / 0)
                 const float cj0 = (q < 3) ? 1.0f : 0.0f;
@@ -247,28 +273,51 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
     // epilogue.  The products are formed transposed (A operand = weights, B operand = V), so in the
     // C/D layout of a 16x16 tile (col = lane & 15, row = 4 * (lane >> 4) + reg) a lane holds FOUR
     // CONSECUTIVE output channels of ONE wtile: one 16-byte load / store per output cell.
+    auto finish = [&](const f32x4 yv, const f32x4 bv, int y, int x, long board, int c0) {
+        if (y < S && x < S) {
+            const long off = (board * P + y * S + x) * 128 + c0;
+            f32x4 v = yv + bv;
+            if (RESID) v += *reinterpret_cast<const f32x4*>(&resid[off]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
+            *reinterpret_cast<f32x4*>(&out[off]) = v;
+        }
+    };
     const int col = wave * 16 + 4 * lq;
     const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col]);
 #pragma unroll
-    for (int t = 0; t < MT; t++) {
+    for (int t = 0; t < (W::USE4 ? 6 : MT); t++) {
         const int w = t * 16 + li;
-        const int bl = w / W::T2, rem = w - bl * W::T2;
+        int bl, rem;
+        if constexpr (W::USE4) { bl = w / W::MAIN; rem = w - bl * W::MAIN; }
+        else { bl = w / W::T2; rem = w - bl * W::T2; }
         const long board = b_first + bl;
         if (w >= W::WT || board >= nboards) continue;
         const int ty = rem / W::T, tx = rem - ty * W::T;
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int y = 2 * ty + i, x = 2 * tx + j;
-                if (y < S && x < S) {
-                    const long off = (board * P + y * S + x) * 128 + col;
-                    f32x4 v = Y[i][j][t] + bv;
-                    if (RESID) v += *reinterpret_cast<const f32x4*>(&resid[off]);
+            for (int j = 0; j < 2; j++) finish(Y[i][j][t], bv, 2 * ty + i, 2 * tx + j, board, col);
+    }
+    if constexpr (W::USE4) {
+        // the 4x4 blocks: a lane holds channels 4 (li / 4) .. + 3 of tail row li % 4 for its k slice; the four
+        // slices (lanes l, l ^ 16, l ^ 32, l ^ 48) are summed in a fixed order, lanes 0..15 store
+        const int col2 = wave * 16 + (li & 12), k4 = li & 3;
+        const f32x4 bv2 = *reinterpret_cast<const f32x4*>(&bias[col2]);
+        const int bl = k4 / W::TPB, rem = W::MAIN + k4 - bl * W::TPB;
+        const long board = b_first + bl;
+        const int ty = rem / W::T, tx = rem - ty * W::T;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
-                    *reinterpret_cast<f32x4*>(&out[off]) = v;
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                f32x4 v = Y[i][j][6];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    v[e] += __shfl_xor(v[e], 16);
+                    v[e] += __shfl_xor(v[e], 32);
                 }
+                if (lq == 0 && k4 < W::TAIL && board < nboards) finish(v, bv2, 2 * ty + i, 2 * tx + j, board, col2);
             }
     }
     W_STAMP(5);
