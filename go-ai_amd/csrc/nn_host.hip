@@ -66,15 +66,17 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
         // kernels round differently).  GOAI_CONV_ALGO=direct / wino forces one of them.
         const char* algo = getenv("GOAI_CONV_ALGO");
         n.wino_mode = 0;
+        {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                prop.multiProcessorCount > 0)
+                n.n_cu = prop.multiProcessorCount;
+        }
         if (dtype == GOAI_DTYPE_F32) {
             if (algo && std::string(algo) == "wino") n.wino_mode = 2;
             else if (algo && std::string(algo) == "wino3" && wino3_supported(c->S)) n.wino_mode = 3;
             else if (!(algo && std::string(algo) == "direct") && c->S >= 9) {
-                int dev = 0;
-                hipDeviceProp_t prop;
-                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-                    prop.multiProcessorCount > 0)
-                    n.n_cu = prop.multiProcessorCount;
                 // one workgroup per CU and round: Winograd when the last round is at least 3/4 full
                 const int nbw = wino_boards_per_wg(c->S);
                 const int grid = (max_batch + nbw - 1) / nbw, rounds = (grid + n.n_cu - 1) / n.n_cu;

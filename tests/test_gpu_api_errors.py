@@ -14,6 +14,8 @@ def test_search_call_sequence_errors():
     c = Context(5)
     with pytest.raises(_hip.GoaiError, match="nn_init"):
         c.nn_conv_algo()
+    with pytest.raises(_hip.GoaiError, match="nn_init"):
+        c.nn_convs_per_launch()
     with pytest.raises(_hip.GoaiError, match="mcts_init"):
         c.mcts_reset(np.zeros((1, 6, 5, 5), np.uint8))
     with pytest.raises(_hip.GoaiError, match="max_sims"):
