@@ -16,6 +16,7 @@
 // transposed products, the whole residual trunk in one launch) is as in conv_wino3_kernels.hip.
 // The summation order differs from that kernel (64 channels per accumulator instead of 32), so a
 // context uses one or the other for its whole life (nn_host.hip).
+#include <type_traits>
 #include "go_board.h"
 #include "goai_internal.h"
 #include "nn.h"
@@ -39,6 +40,20 @@ struct Wino3P {
     static_assert(LDS_U4 * 16 <= 160 * 1024, "LDS budget");
     static_assert(IMG_CH_U4 * 16 < 65536, "cell addresses and the chunk offset are 16-bit");
 };
+
+#ifdef GOAI_CONV_STAMPS
+// diagnostic build only (tools/wino3p_stamps.py): s_memrealtime (100 MHz) stamps of the SECOND convolution of
+// a launch, 32 per workgroup: 0 layer top, 1 image staged, 2 + 2r transform of row r done (r = 5 cp + p),
+// 3 + 2r its stages done, 22 epilogue done; 23 / 24 = s_memtime (shader clock) at stamps 0 / 22
+__device__ unsigned long long g_wino3p_stamps[32 * 1024];
+extern "C" int goai_debug_wino3p_stamps(unsigned long long* host_out, int n)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino3p_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#define W3P_STAMP(i) if (threadIdx.x == 0 && k == 1) { g_wino3p_stamps[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); if ((i) == 0 || (i) == 22) g_wino3p_stamps[blockIdx.x * 32 + 23 + ((i) == 22)] = __builtin_amdgcn_s_memtime(); }
+#else
+#define W3P_STAMP(i)
+#endif
 
 __device__ __forceinline__ f32x4 p_fma4(float c, f32x4 a, f32x4 b)
 {
@@ -169,6 +184,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3p(float* x, float* y, cons
     // k = 0: the zero fills and the table are complete; k > 0: every wave's MFMAs of the previous
     // convolution have read V and its stores to `in` are visible to this workgroup
     __syncthreads();
+    W3P_STAMP(0);
     {
         f32x4 ireg1[W::NI];                          // both chunks in flight at once: the accumulators are not live yet
         load_img(0);
@@ -183,6 +199,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3p(float* x, float* y, cons
         for (int j = 0; j < 3; j++)
 #pragma unroll
             for (int t = 0; t < MT; t++) Y[i][j][t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    W3P_STAMP(1);
 
 #pragma unroll 1
     for (int cp = 0; cp < 2; cp++) {
@@ -193,6 +210,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3p(float* x, float* y, cons
             transform(p, 0);
             transform(p, 1);
             __syncthreads();                                   // V complete; (p == 4) the image is dead
+            W3P_STAMP(2 + 2 * (5 * cp + p));
             if (stage_next) {
                 store_img(0);
                 load_img(3);
@@ -261,6 +279,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3p(float* x, float* y, cons
                 }
             }
             __syncthreads();                                   // every wave has read this row of V
+            W3P_STAMP(3 + 2 * (5 * cp + p));
             if (stage_next) {
                 store_img(1);
                 __syncthreads();
@@ -273,33 +292,51 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3p(float* x, float* y, cons
     // CONSECUTIVE output channels of ONE wtile: one 16-byte load / store per output cell.  In the 4x4
     // blocks a lane holds channels 4 (li / 4) .. + 3 of wtile row 32 + li % 4 for its k slice: the four
     // slices (lanes l, l ^ 16, l ^ 32, l ^ 48) are summed in a fixed order, lanes 0..15 store.
-    auto finish = [&](const f32x4 yv, const f32x4 bv, long off) {
-        f32x4 v = yv + bv;
-        if (resid) v += *reinterpret_cast<const f32x4*>(&resid[off]);
+    // `out` may alias `resid` (the trunk's in-place convolutions), so loads and stores stay in program
+    // order: load -> add -> store per cell is 27 dependent round trips (12 us of a 110 us layer at any
+    // grid size, tools/wino3p_stamps.py).  The nine residual loads of a row tile are issued together,
+    // and the residual / no-residual choice is made once, not per cell.
+    auto epilogue = [&](auto has_resid) {
+        constexpr bool R = decltype(has_resid)::value;
+        auto tile = [&](const f32x4 (&yv)[3][3], const f32x4 bv, long base, bool on) {
+            // base = element offset of output (0, 0) of the wtile, this lane's channels
+            if (!on) return;
+            f32x4 rv[3][3];
+            if (R) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
-        *reinterpret_cast<f32x4*>(&out[off]) = v;
-    };
-    {
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) rv[i][j] = *reinterpret_cast<const f32x4*>(&resid[base + (i * S + j) * 128]);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    f32x4 v = yv[i][j] + bv;
+                    if (R) v += rv[i][j];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
+                    *reinterpret_cast<f32x4*>(&out[base + (i * S + j) * 128]) = v;
+                }
+        };
         const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col]);
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             const int w = t * 16 + li;
             const int bl = w >> 3, wt = w & 7;
             const long board = b_first + bl;
-            if (board >= nboards) continue;
             const int ty = wt / W::T, tx = wt - ty * W::T;
+            f32x4 yv[3][3];
 #pragma unroll
             for (int i = 0; i < 3; i++)
 #pragma unroll
-                for (int j = 0; j < 3; j++)
-                    finish(Y[i][j][t], bv, (board * P + (3 * ty + i) * S + 3 * tx + j) * 128 + col);
+                for (int j = 0; j < 3; j++) yv[i][j] = Y[i][j][t];
+            tile(yv, bv, (board * P + 3 * ty * S + 3 * tx) * 128 + col, board < nboards);
         }
-    }
-    {
         const int col2 = wave * 16 + (li & 12);
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col2]);
-        const long board = b_first + (li & 3);
+        const f32x4 bv2 = *reinterpret_cast<const f32x4*>(&bias[col2]);
+        const long board2 = b_first + (li & 3);
+        f32x4 yv[3][3];
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -310,10 +347,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3p(float* x, float* y, cons
                     v[e] += __shfl_xor(v[e], 16);
                     v[e] += __shfl_xor(v[e], 32);
                 }
-                if (lq == 0 && board < nboards)          // wtile 8 = (ty, tx) = (2, 2)
-                    finish(v, bv, (board * P + (6 + i) * S + 6 + j) * 128 + col2);
+                yv[i][j] = v;
             }
-    }
+        tile(yv, bv2, (board2 * P + 6 * S + 6) * 128 + col2, lq == 0 && board2 < nboards);   // wtile 8 = (ty, tx) = (2, 2)
+    };
+    if (resid) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
+    W3P_STAMP(22);
     // next convolution of the launch: swap the buffers, step the weights
     if (k & 1) { in = x; out = y; resid = resid0; } else { in = y; out = x; resid = x; }
     wsrc += (size_t)25 * 128 * 128;
