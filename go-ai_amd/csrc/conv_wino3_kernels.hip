@@ -20,6 +20,7 @@
 //   - NBW = 4 boards = 36 wtiles in MT = 3 MFMA row tiles (48 rows) per 512-thread workgroup,
 //   - 5 x 5 transform positions: 4 chunks x 5 rows p x 5 columns q = 100 stages of 24 MFMAs per wave,
 //   - nine output accumulator sets + one M in flight per wave (120 registers).
+#include <type_traits>
 #include "go_board.h"
 #include "goai_internal.h"
 #include "nn.h"
@@ -303,26 +304,41 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(float* x, float* y, const
     // epilogue.  The products are formed transposed (A operand = weights, B operand = V), so in the
     // C/D layout of a 16x16 tile (col = lane & 15, row = 4 * (lane >> 4) + reg) a lane holds FOUR
     // CONSECUTIVE output channels of ONE wtile: one 16-byte load / store per output cell.
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col]);
+    // `out` may alias `resid` (the in-place convolutions of a trunk launch), so loads and stores stay in
+    // program order: load -> add -> store per cell would be 27 dependent round trips.  The residual /
+    // no-residual choice is made once and a row tile's nine residual loads are issued together.
+    auto epilogue = [&](auto has_resid) {
+        constexpr bool R = decltype(has_resid)::value;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col]);
 #pragma unroll
-    for (int t = 0; t < MT; t++) {
-        const int w = t * 16 + li;
-        const int bl = w / W::T2, rem = w - bl * W::T2;
-        const long board = b_first + bl;
-        if (w >= W::WT || board >= nboards) continue;
-        const int ty = rem / W::T, tx = rem - ty * W::T;
+        for (int t = 0; t < MT; t++) {
+            const int w = t * 16 + li;
+            const int bl = w / W::T2, rem = w - bl * W::T2;
+            const long board = b_first + bl;
+            if (w >= W::WT || board >= nboards) continue;
+            const int ty = rem / W::T, tx = rem - ty * W::T;
+            const long base = (board * P + 3 * ty * S + 3 * tx) * 128 + col;
+            f32x4 rv[3][3];
+            if (R) {
 #pragma unroll
-        for (int i = 0; i < 3; i++)
+                for (int i = 0; i < 3; i++)
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const long off = (board * P + (3 * ty + i) * S + 3 * tx + j) * 128 + col;
-                f32x4 v = Y[i][j][t] + bv;
-                if (resid) v += *reinterpret_cast<const f32x4*>(&resid[off]);
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
-                *reinterpret_cast<f32x4*>(&out[off]) = v;
+                    for (int j = 0; j < 3; j++) rv[i][j] = *reinterpret_cast<const f32x4*>(&resid[base + (i * S + j) * 128]);
             }
-    }
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    f32x4 v = Y[i][j][t] + bv;
+                    if (R) v += rv[i][j];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
+                    *reinterpret_cast<f32x4*>(&out[base + (i * S + j) * 128]) = v;
+                }
+        }
+    };
+    if (resid) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
     W3_STAMP(5);
     // next convolution of the launch: swap the buffers, step the weights
     if (k & 1) { in = x; out = y; resid = resid0; } else { in = y; out = x; resid = x; }
