@@ -185,13 +185,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3(float* x, float* y, const
         V[w3swz(4 * ROWS + ttw, ts)] = fma4(-2.0f, r[3], fma4(2.0f, r[1], r[4] - r[2]));
     };
 
-    // weight fragments of a stage: U[stage][cout = 16 wave + li][32 in], k = kk*16 + lq*4 + jj
-    const float* wsrc = wt_all + (size_t)(wave * 16 + li) * 32 + lq * 4;
+    // weight fragments of a stage: U[stage] in the lanes' own order (nn_host.hip): lane (li, lq) gets channel
+    // cout = 16 wave + li, inputs k = kk*16 + lq*4 + jj
+    const float* wsrc = wt_all + wave * 512 + lane * 4;   // [stage][wave][kk][lane][4] (nn_host.hip): whole lines per load
     f32x4 bcur[2], bnxt[2];
     auto load_b = [&](int stage, f32x4* b) {
         const float* src = wsrc + (size_t)stage * 128 * 32;
         b[0] = *reinterpret_cast<const f32x4*>(src);
-        b[1] = *reinterpret_cast<const f32x4*>(src + 16);
+        b[1] = *reinterpret_cast<const f32x4*>(src + 256);
     };
 
     f32x4 Y[3][3][MT];                               // [i][j]: output (3ty + i, 3tx + j) of the wtile

@@ -244,8 +244,12 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
                             double u = 0.0;
                             for (int ky = 0; ky < 3; ky++)
                                 for (int kx = 0; kx < 3; kx++) u += G3[pp][ky] * G3[qq][kx] * (double)g[ky * 3 + kx];
+                            // [stage][wave = co / 16][kk][lane = 16 lq + li][jj], k = 16 kk + 4 lq + jj: exactly the MFMA
+                            // operand registers of the kernels' lanes, so a wave's weight load is 1 KB of whole lines
                             const int chunk = ci / 32, k = ci % 32;
-                            wu[((((size_t)chunk * 25 + pp * 5 + qq) * 128) + co) * 32 + k] = (float)(u * sc[co]);
+                            const size_t lane = (size_t)((k % 16) / 4) * 16 + co % 16;
+                            wu[((size_t)chunk * 25 + pp * 5 + qq) * 4096 + (size_t)(co / 16) * 512 + (k / 16) * 256 + lane * 4 + k % 4] =
+                                (float)(u * sc[co]);
                         }
                 }
             GOAI_HIP_CHECK(hipMemcpy(net.wt_wino3 + (size_t)l * 25 * 128 * 128, wu.data(), wu.size() * sizeof(float),
@@ -264,7 +268,10 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
                             for (int ky = 0; ky < 3; ky++)
                                 for (int kx = 0; kx < 3; kx++) u += Gm[pp][ky] * Gm[qq][kx] * (double)g[ky * 3 + kx];
                             const int chunk = ci / 32, k = ci % 32;
-                            wu[((((size_t)chunk * 16 + pp * 4 + qq) * 128) + co) * 32 + k] = (float)(u * sc[co]);
+                            // the lanes' own order, as for F(3x3,3x3) above
+                            const size_t lane = (size_t)((k % 16) / 4) * 16 + co % 16;
+                            wu[((size_t)chunk * 16 + pp * 4 + qq) * 4096 + (size_t)(co / 16) * 512 + (k / 16) * 256 + lane * 4 + k % 4] =
+                                (float)(u * sc[co]);
                         }
                 }
             GOAI_HIP_CHECK(hipMemcpy(net.wt_wino + (size_t)l * 16 * 128 * 128, wu.data(), wu.size() * sizeof(float),
