@@ -63,13 +63,15 @@ def test_replay_reference_search_fed_logits(name):
         assert np.array_equal(prior[i], mcts_ref.det_softmax32(cs["pi_logits"][0]).astype(np.float64))
 
 
-@pytest.mark.parametrize("size,n_games,sims", [(5, 24, 8), (9, 16, 81), (13, 4, 40)])
-def test_full_search_matches_oracle(size, n_games, sims):
+@pytest.mark.parametrize("size,n_games,sims,layers", [(5, 24, 8, 3), (9, 16, 81, 3), (13, 4, 40, 3),
+                                                      (19, 2, 30, 10),      # BASELINE.json configs[4]: 362 actions, deeper CNN
+                                                      (19, 3, 81, 3)])
+def test_full_search_matches_oracle(size, n_games, sims, layers):
     """GPU search with its own CNN vs the sequential oracle fed the same NN outputs."""
     from go_ai.engine import Context
     c = Context(size)
-    c.nn_init(Context.NET_AC, 3, n_games)
-    sd = nn_ref.make_state_dict("ac", size, 40 + size)
+    c.nn_init(Context.NET_AC, layers, n_games)
+    sd = nn_ref.make_state_dict("ac", size, 40 + size, layers)
     c.load_weights(sd)
     c.mcts_init(n_games, sims)
     roots = random_positions(size, n_games, seed=300 + size, max_moves=size * size // 2, canonical=True,

@@ -74,7 +74,8 @@ def _stepwise(c, sims, log=None):
                         kv.cpu().numpy().reshape(n_games, A)))
 
 
-@pytest.mark.parametrize("size,n_games,sims,kind", [(5, 16, 10, "val"), (9, 12, 8, "val"), (9, 4, 5, "ac"), (13, 3, 4, "val")])
+@pytest.mark.parametrize("size,n_games,sims,kind", [(5, 16, 10, "val"), (9, 12, 8, "val"), (9, 4, 5, "ac"), (13, 3, 4, "val"),
+                                                   (19, 2, 3, "val")])     # 362 actions: six ballot words per node
 def test_full_q_search_matches_oracle(size, n_games, sims, kind):
     from go_ai.engine import Context
     sd = nn_ref.make_state_dict(kind, size, 70 + size)

@@ -90,6 +90,27 @@ def test_batched_selfplay_runs_games_to_the_end():
     assert 0 < st["leaf_evals"] <= 64 * 7 * 52
 
 
+def test_batched_selfplay_19x19_runs_games_to_the_end():
+    """BASELINE.json configs[4]'s board: k_mcts_select / backup / policy / sample / advance at S = 19
+    (362 actions, six actions per lane) over whole games, to the 2 * 361 move cap (game.py:74,98); the
+    final result of every game is the area score of its final position on the CPU oracle's rules."""
+    from go_ai.game import BatchedSelfPlay
+    from oracle.gogame import GoGame as OG
+    n = 6
+    sp = BatchedSelfPlay(19, n, 2, seed=5)
+    sp.randomize_starts(250)
+    sp.play(2 * 361 + 2)
+    st = sp.stats()
+    assert st["finished"] == n and st["errors"] == 0
+    states, turn, moves, result = [t.cpu().numpy() for t in sp.ctx.mcts_roots()]
+    assert (moves <= 2 * 361 + 1).all() and (moves > 0).all()
+    for g in range(n):
+        b, w = OG.areas(states[g].astype(np.float64))          # canonical: plane 0 = the side to move
+        sign = int(np.sign(b - w))
+        assert result[g] == (-sign if turn[g] else sign)
+        assert OG.game_ended(states[g].astype(np.float64)) or moves[g] == 2 * 361 + 1
+
+
 def test_value_policy_q_search_matches_golden():
     """policies.Value with mcts > 0 driven by a host critic (the reference's recorded outputs)."""
     from golden_util import ReplayCritic
