@@ -21,7 +21,7 @@ using namespace goai;
 extern "C" {
 
 const char* goai_last_error(void) { return g_last_error.c_str(); }
-int goai_version(void) { return 2; }
+int goai_version(void) { return 3; }
 
 int goai_ctx_create(goai_ctx** out, int device, int board_size)
 {
@@ -31,6 +31,10 @@ int goai_ctx_create(goai_ctx** out, int device, int board_size)
     GOAI_HIP_CHECK(hipGetDeviceCount(&ndev));
     GOAI_REQUIRE(device >= 0 && device < ndev, "no such GPU");
     GOAI_HIP_CHECK(hipSetDevice(device));
+    {
+        const int rc = nn_static_setup(device);   // device address of goai_nn_forward_static's buffers, once per GPU
+        if (rc) return rc;
+    }
     goai_ctx* c = new (std::nothrow) goai_ctx();
     GOAI_REQUIRE(c != nullptr, "out of host memory");
     c->device = device;
@@ -144,6 +148,21 @@ int goai_nn_forward(goai_ctx* ctx, const uint8_t* states, float* pi_logits, floa
     GOAI_REQUIRE(states && val_logits, "NULL array argument");
     GOAI_REQUIRE(ctx->net.kind == 0 || pi_logits == nullptr, "the value net has no policy head");
     int rc = nn_forward_raw(ctx, states, pi_logits, val_logits, n);
+    if (rc) return rc;
+    if (mode == GOAI_NN_NUMPY_SHIM) rc = launch_numpy_shim(ctx->S, states, pi_logits, val_logits, n, ctx->stream);
+    return rc;
+}
+
+int goai_nn_forward_static(goai_ctx* ctx, const uint8_t* states, float* pi_logits, float* val_logits, int n, int mode)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(n >= 0, "n < 0");
+    GOAI_REQUIRE(mode == GOAI_NN_RAW || mode == GOAI_NN_NUMPY_SHIM, "unknown mode");
+    if (n == 0) return GOAI_OK;
+    GOAI_REQUIRE(states && val_logits, "NULL array argument");
+    GOAI_REQUIRE(ctx->net.kind >= 0, "call goai_nn_init first");
+    GOAI_REQUIRE(ctx->net.kind == 0 || pi_logits == nullptr, "the value net has no policy head");
+    int rc = nn_forward_static(ctx, states, pi_logits, val_logits, n);
     if (rc) return rc;
     if (mode == GOAI_NN_NUMPY_SHIM) rc = launch_numpy_shim(ctx->S, states, pi_logits, val_logits, n, ctx->stream);
     return rc;

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -360,23 +361,27 @@ static int timed_conv(goai_ctx* c, const float* in, int l, const float* b, const
     return rc;
 }
 
-// Raw network outputs for n states (pi may be NULL; always NULL-able for the value net).
-int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, int n)
+// Raw network outputs for n states (pi may be NULL; always NULL-able for the value net), through the three
+// activation buffers `act` of `cap` boards each.  `timed`: bracket the trunk launches with HIP events
+// when the context's profile is on (creates events, so not for the allocation-free entry point).
+static int nn_forward_on(goai_ctx* c, float* const act[3], int cap, bool timed, const uint8_t* states, float* pi,
+                         float* val, int n)
 {
     Net& net = c->net;
     GOAI_REQUIRE(net.loaded, "weights not loaded (goai_load_weights)");
     const int P = c->P, A = c->A;
-    for (int done = 0; done < n; done += net.max_batch) {
-        const int nb = (n - done) < net.max_batch ? (n - done) : net.max_batch;
+    const bool prof = timed && c->prof_enabled;
+    for (int done = 0; done < n; done += cap) {
+        const int nb = (n - done) < cap ? (n - done) : cap;
         const int M = nb * P;
         int rc;
-        if ((rc = launch_conv0(c->S, states + (size_t)done * 6 * P, net.w0, net.w0_split, net.b0, net.shift, net.act[0], nb, c->stream)))
+        if ((rc = launch_conv0(c->S, states + (size_t)done * 6 * P, net.w0, net.w0_split, net.b0, net.shift, act[0], nb, c->stream)))
             return rc;
-        float *x = net.act[0], *y = net.act[1], *z = net.act[2];
+        float *x = act[0], *y = act[1], *z = act[2];
         if (net.trunk_fused && net.layers > 0) {
             // F(3x3,3x3): a workgroup owns whole boards, so all 2 * layers convolutions run in one launch
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (c->prof_enabled) {
+            if (prof) {
                 GOAI_HIP_CHECK(hipEventCreate(&e0));
                 GOAI_HIP_CHECK(hipEventCreate(&e1));
                 c->prof_events.push_back(e0);
@@ -392,8 +397,13 @@ int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, in
             if (rc) return rc;
         } else
         for (int l = 0; l < net.layers; l++) {
-            if ((rc = timed_conv(c, x, 2 * l, net.bt + (size_t)(2 * l) * 128, nullptr, y, M))) return rc;
-            if ((rc = timed_conv(c, y, 2 * l + 1, net.bt + (size_t)(2 * l + 1) * 128, x, z, M))) return rc;
+            if (prof) {
+                if ((rc = timed_conv(c, x, 2 * l, net.bt + (size_t)(2 * l) * 128, nullptr, y, M))) return rc;
+                if ((rc = timed_conv(c, y, 2 * l + 1, net.bt + (size_t)(2 * l + 1) * 128, x, z, M))) return rc;
+            } else {
+                if ((rc = conv_any(c, x, 2 * l, net.bt + (size_t)(2 * l) * 128, nullptr, y, M))) return rc;
+                if ((rc = conv_any(c, y, 2 * l + 1, net.bt + (size_t)(2 * l + 1) * 128, x, z, M))) return rc;
+            }
             float* t = x; x = z; z = t;
         }
         if ((rc = launch_heads(c->S, x, net.hw, net.kind == 0 && pi != nullptr, pi ? pi + (size_t)done * A : nullptr, val + done, nb,
@@ -401,6 +411,49 @@ int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, in
             return rc;
     }
     return GOAI_OK;
+}
+
+int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, int n)
+{
+    return nn_forward_on(c, c->net.act, c->net.max_batch, true, states, pi, val, n);
+}
+
+// ---- the allocation-free forward (goai_nn_forward_static) --------------------------------------
+// The three activation buffers of a small batch live in a file-scope device array instead of the
+// context's hipMalloc'ed ones: NN_STATIC_ROWS board cells x 128 channels x fp32 x 3 = 12 MiB, held by
+// every GPU the library runs on until the process ends.  `scratch` is only a host-side handle here: its
+// device address is looked up once per device (nn_static_setup, called by goai_ctx_create with that
+// device current) and everything below uses that pointer.
+static __device__ __align__(256) float scratch[3 * GOAI_NN_STATIC_MAX_CELLS * 128];
+static std::mutex g_scratch_mutex;
+static float* g_scratch_ptr[64];          // per device
+
+int nn_static_setup(int device)
+{
+    GOAI_REQUIRE(device >= 0 && device < 64, "device index out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return GOAI_OK;
+    float* p = nullptr;
+    GOAI_HIP_CHECK(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+    GOAI_REQUIRE(p != nullptr, "hipGetSymbolAddress returned NULL for the static activation buffers");
+    g_scratch_ptr[device] = p;
+    return GOAI_OK;
+}
+
+int nn_forward_static(goai_ctx* c, const uint8_t* states, float* pi, float* val, int n)
+{
+    GOAI_REQUIRE(c->device >= 0 && c->device < 64 && g_scratch_ptr[c->device] != nullptr,
+                 "static activation buffers were not set up on this device");
+    if ((size_t)n * c->P > (size_t)GOAI_NN_STATIC_MAX_CELLS) {
+        set_error("goai_nn_forward_static: n * S * S = " + std::to_string((size_t)n * c->P) + " board cells exceed "
+                  "GOAI_NN_STATIC_MAX_CELLS = " + std::to_string(GOAI_NN_STATIC_MAX_CELLS) + "; use goai_nn_forward");
+        return GOAI_ERR_ARG;
+    }
+    float* base = g_scratch_ptr[c->device];
+    float* const act[3] = { base, base + (size_t)GOAI_NN_STATIC_MAX_CELLS * 128, base + (size_t)2 * GOAI_NN_STATIC_MAX_CELLS * 128 };
+    const int cap_static = GOAI_NN_STATIC_MAX_CELLS / c->P;
+    const int cap = cap_static < c->net.max_batch ? cap_static : c->net.max_batch;
+    return nn_forward_on(c, act, cap, false, states, pi, val, n);
 }
 
 }  // namespace goai

@@ -41,6 +41,7 @@ _SIGNATURES = {
     "goai_nn_conv_algo": [c_void_p],
     "goai_nn_convs_per_launch": [c_void_p],
     "goai_nn_forward": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int],
+    "goai_nn_forward_static": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int],
     "goai_mcts_init": [c_void_p, c_int, c_int, c_int],
     "goai_mcts_reset": [c_void_p, c_void_p],
     "goai_mcts_select": [c_void_p, c_void_p],

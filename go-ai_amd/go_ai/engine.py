@@ -145,6 +145,16 @@ class Context:
         _hip.check(_hip.lib.goai_nn_forward(self._h, _hip.ptr(st), _hip.ptr(pi), _hip.ptr(val), n, int(mode)))
         return pi, val
 
+    NN_STATIC_MAX_CELLS = 8192
+
+    def nn_forward_static(self, states, pi, val, mode=0):
+        """goai_nn_forward_static: the forward of `states` (a uint8 DEVICE tensor) into the caller's
+        `pi` ([n, A] float32 or None) and `val` ([n, 1] float32) without any allocation: the
+        activations live in the library's static device array (n * size**2 <= NN_STATIC_MAX_CELLS)."""
+        assert states.is_cuda and states.dtype == torch.uint8 and states.is_contiguous()
+        n = states.shape[0]
+        _hip.check(_hip.lib.goai_nn_forward_static(self._h, _hip.ptr(states), _hip.ptr(pi), _hip.ptr(val), n, int(mode)))
+
     # ---- batched search ------------------------------------------------------------
     SEARCH_AC, SEARCH_Q = 0, 1
 

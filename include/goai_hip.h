@@ -141,6 +141,20 @@ int goai_load_weights(goai_ctx* ctx, const char* const* names, const float* cons
 int goai_nn_forward(goai_ctx* ctx, const uint8_t* states, float* pi_logits, float* val_logits, int n,
                     int mode);
 
+/* goai_nn_forward for callers that cannot allocate -- code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference.  Same arguments,
+ * kernels and results (bit for bit) as goai_nn_forward on the same context, but the activation
+ * buffers between the kernels are a file-scope device array of the library (12 MiB per GPU, held
+ * until the process ends) instead of the context's hipMalloc'ed ones, and the call allocates nothing
+ * (no hipMalloc / hipFree / event creation; goai_profile_* does not see it).  Limit:
+ * n * S * S <= GOAI_NN_STATIC_MAX_CELLS board cells (101 boards of 9x9, 48 of 13x13, 22 of 19x19);
+ * larger n is rejected with GOAI_ERR_ARG.  All contexts of one GPU share the array and it keeps the
+ * last call's contents (nothing in it has to start at zero): calls that overlap on one GPU --
+ * different streams or host threads -- race; calls on one stream are ordered. */
+#define GOAI_NN_STATIC_MAX_CELLS 8192
+int goai_nn_forward_static(goai_ctx* ctx, const uint8_t* states, float* pi_logits, float* val_logits, int n,
+                           int mode);
+
 /* ---------------------------------------------------------------------------------------
  * Batched Monte-Carlo tree search: n_games independent games per context, one tree each,
  * advanced in lock step (one leaf per game per step).
