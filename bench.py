@@ -9,7 +9,10 @@ passes of  select -> Go transition -> CNN forward over the 1024-leaf batch -> ex
 plus the temperature policy, action sampling and the move itself.  Everything inside the
 timed region runs on the GPU from HBM-resident state.
 
-    python bench.py [--gpus N --steps K --warmup W]      (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+        N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+        (WORLD_SIZE set: this process is one rank) or run plainly, and then bench.py starts the N ranks
+        itself as a child torch.distributed.run.
 
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how each field is obtained.
 """
@@ -49,10 +52,11 @@ CONFIGS = {
 # multi_proc_play (/root/reference/go_ai/utils.py:211-232).  Runs BEFORE the GPU is touched.
 # --------------------------------------------------------------------------------------
 def _cpu_worker(args):
-    wid, seconds = args
+    wid, seconds, threads = args
     import numpy as np
     import torch
-    torch.set_num_threads(1)
+    if threads:
+        torch.set_num_threads(threads)
     from oracle import mcts_ref, nn_ref
     from oracle.gogame import GoEnv, GoGame
     sd = nn_ref.make_state_dict("ac", SIZE, 0, LAYERS)
@@ -80,23 +84,141 @@ def _cpu_worker(args):
         pi, _, _ = mcts_ref.actor_critic_policy(env, ac, SIMS, 1.0, math="numpy")
         env.step(GoGame.random_weighted_action(pi))
         moves += 1
-    return evals, time.perf_counter() - t0, moves
+    return evals, time.perf_counter() - t0, moves, torch.get_num_threads()
+
+
+def host_cpu_share():
+    """How many host cores this process may really use: the smallest of the scheduler affinity, the
+    cgroup CPU quota and the harness's worker-pool hint (OMP_NUM_THREADS / MAX_JOBS: the GPU box exports
+    its per-GPU CPU share there while nproc shows the whole machine).  Returns (cores, explanation)."""
+    on_box = os.cpu_count() or 1
+    limits = {"os.cpu_count": on_box}
+    try:
+        limits["sched_getaffinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            limits["cgroup cpu.max"] = max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                limits["cgroup cfs_quota"] = max(1, q // per)
+        except (OSError, ValueError):
+            pass
+    for var in ("OMP_NUM_THREADS", "MAX_JOBS"):
+        v = os.environ.get(var, "")
+        if v.isdigit() and int(v) > 0:
+            limits[var] = int(v)
+    if os.environ.get("GOAI_CPU_WORKERS", "").isdigit():
+        limits = {"GOAI_CPU_WORKERS": int(os.environ["GOAI_CPU_WORKERS"]), "os.cpu_count": on_box}
+        return max(1, limits["GOAI_CPU_WORKERS"]), limits
+    return max(1, min(limits.values())), limits
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(seconds):
+    """All-cores figure (the one the >= 1000x target is judged on): one
+    single-threaded worker process per usable core, independent games, like the reference's
+    multi_proc_play; then the reference's per-process figure: ONE process with torch's default
+    thread count."""
     import multiprocessing as mp
     from oracle import gogame
     gogame.build()
-    cores = max(1, min(16, os.cpu_count() or 1))
+    cores, limits = host_cpu_share()
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(w, seconds) for w in range(cores)])
-    value = sum(e / t for e, t, _ in res)
+        res = pool.map(_cpu_worker, [(w, seconds, 1) for w in range(cores)])
+    with ctx.Pool(1) as pool:
+        one = pool.map(_cpu_worker, [(0, max(4.0, seconds / 2), 0)])[0]
+    value = sum(e / t for e, t, _, _ in res)
     return {"value": round(value, 2), "unit": "leaf evals/s", "cores": cores, "kind": "port",
             "per_core": round(value / cores, 2),
+            "cores_on_box": limits["os.cpu_count"], "core_limits": limits, "cpu_model": cpu_model(),
+            "one_process": {"value": round(one[0] / one[1], 2), "torch_num_threads": one[3],
+                            "sample": f"1 process x {one[1]:.0f} s, {one[2]} moves, {one[0]} leaf evals"},
             "sample": f"{cores} single-threaded worker processes x {seconds:.0f} s of whole moves "
                       f"(9x9 AC, mcts={SIMS}, oracle search + batch-1 torch CPU forward), "
-                      f"{sum(m for _, _, m in res)} moves, {sum(e for e, _, _ in res)} leaf evals"}
+                      f"{sum(m for _, _, m, _ in res)} moves, {sum(e for e, _, _, _ in res)} leaf evals"}
+
+
+# --------------------------------------------------------------------------------------
+# --gpus N without a launcher: this process (which never touches the GPU) times the CPU baseline,
+# then starts the N ranks itself as a child `torch.distributed.run` -- as the reference's
+# multi_proc_play starts its own workers (/root/reference/go_ai/utils.py:211-232) -- relays rank 0's
+# JSON line and attaches the baseline to it.
+# --------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args, cpu):
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--config", args.config,
+           "--dtype", args.dtype, "--groups", str(args.groups), "--no-cpu-baseline"]
+    if args.games:
+        cmd += ["--games", str(args.games)]
+    if args.backend != "nccl":
+        cmd += ["--backend", args.backend]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        sys.stderr.write(proc.stdout)
+        raise SystemExit(f"bench.py: the {args.gpus}-rank child run failed (exit code {proc.returncode})")
+    out = json.loads(line)
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+        out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 1)
+    print(json.dumps(out), flush=True)
+
+
+def gloo_rehearsal(args, rank, world):
+    """--backend gloo: the N-rank path without a GPU -- rendezvous, game sharding by rank, barriers, the
+    single gather, max-over-ranks time, rank 0's JSON line -- with a stub in place of the search."""
+    import torch.distributed as dist
+    from go_ai.sharding import gather_stats, reduce_stats, shard_games
+    if world > 1:
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == args.gpus
+    n_games = args.games or CONFIGS[args.config]["games"]
+    lo, hi = shard_games(n_games * world, world, rank)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    evals = (hi - lo) * (SIMS + 1) * args.steps          # what the search would have counted
+    time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tot = reduce_stats(gather_stats(dict(leaf_evals=evals, seconds=elapsed, games=hi - lo)))
+    if rank == 0:
+        print(json.dumps({"metric": "rehearsal (gloo, no GPU work)", "value": round(tot["leaf_evals"] / tot["seconds"], 1),
+                          "unit": "leaf evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "games_total": int(tot["games"]), "leaf_evals": int(tot["leaf_evals"]), "data": "none"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -112,6 +234,8 @@ def main():
                     help="arithmetic of the trunk convolutions: exact fp32 MFMA (default, the reference's precision) "
                          "or split-operand bf16 MFMA (fp32-grade results, see DESIGN.md)")
     ap.add_argument("--groups", type=int, default=1, help="independent game groups on separate HIP streams")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: CPU rehearsal of the N-rank launch / rendezvous / gather path with a stub body (no GPU)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     global SIZE, SIMS, LAYERS
@@ -120,18 +244,27 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    launched = "WORLD_SIZE" in os.environ
+    if launched and world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "c2":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "c2" and args.backend == "nccl":
         cpu = cpu_baseline(args.cpu_seconds)          # before any GPU initialisation
+    if not launched and args.gpus > 1:
+        return launch_ranks(args, cpu)                # child ranks; this process never initialises the GPU
 
     import torch
     import torch.distributed as dist
+
+    if args.backend == "gloo":
+        return gloo_rehearsal(args, rank, world)
     from go_ai.game import BatchedSelfPlay
 
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus
 
     def barrier():
         if world > 1:
@@ -157,7 +290,7 @@ def main():
     my_evals = st["leaf_evals"] - evals0
     assert st["errors"] == 0, st
 
-    # dominant kernel (conv3x3 implicit GEMM): per-launch duration by HIP events on the
+    # dominant kernel (the trunk's 3x3 convolutions): per-launch duration by HIP events on the
     # kernel's own stream over one more move of the same workload
     my_forwards = st["forwards"] - cnt0["forwards"]
     fwd0 = st["forwards"]
@@ -168,12 +301,14 @@ def main():
     else:   # data-dependent batch sizes: rows = states sent through the net during the profiled move
         conv_rows = (sp.counters()["forwards"] - fwd0) * SIZE * SIZE / max(1, conv_n * cpl // (2 * LAYERS))
     conv_flop = 2.0 * conv_rows * 128 * (9 * 128) * cpl              # algorithmic: the convolutions' own multiply-adds
-    achieved = conv_flop / (conv_ms / conv_n * 1e-3) / 1e12
-    peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS / 3.0
+    launch_s = conv_ms / conv_n * 1e-3
+    peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     algo = sp.ctx.nn_conv_algo()
     kname = {0: "k_conv3x3", 1: "k_conv3x3_wino", 2: "k_conv3x3_bf16", 3: "k_conv3x3_wino3", 4: "k_conv3x3_wino3p"}[algo] + f"<{SIZE}>"
-    executed_flop = conv_flop
-    if algo == 1:
+    executed_flop = conv_flop                 # flops the matrix pipe really executes per launch
+    if algo == 2:
+        executed_flop = 3.0 * conv_flop       # hi*hi + lo*hi + hi*lo on the bf16 pipe
+    elif algo == 1:
         # Winograd F(2x2,3x3): 16 products per 2x2 output tile and (cin, cout) instead of 36, on
         # workgroups of 112 tile rows holding NBW whole boards (conv_wino_kernels.hip)
         t2 = ((SIZE + 1) // 2) ** 2
@@ -188,6 +323,12 @@ def main():
         wgs = -(-nb // 4) if -(-nb // 4) <= n_cu else -(-nb // 5)
         # (the two-chunk kernel runs 32 rows as 16x16x4 tiles and the other 4 as 4x4x1 blocks: no padded rows)
         executed_flop = 2.0 * wgs * (36 if algo == 4 else 48) * 25 * 128 * 128 * cpl
+    achieved = executed_flop / launch_s / 1e12           # TFLOP/s the matrix pipe sustains
+    effective = conv_flop / launch_s / 1e12              # the convolution's own flops per second (Winograd executes fewer)
+
+    # the transition side (north_star subsystem 1): k_transition over 65,536 boards taken from the games'
+    # current positions, HIP events on the launch stream; algorithmic bytes = 6P in + 6P out per board
+    tr = sp.profile_transition(65536)
 
     # the one collective of the run: gather per-rank results (utils.py:201-204's allreduces)
     from go_ai.sharding import gather_stats, reduce_stats
@@ -198,10 +339,12 @@ def main():
     total_evals, t_max = tot["leaf_evals"], tot["seconds"]
 
     if rank == 0:
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "conv3x3_traffic.json")
-        if os.path.exists(tpath) and args.config == "c2":          # PMC passes of THIS workload, per kernel
-            traffic = json.load(open(tpath)).get("per_kernel", {}).get(kname.split("<")[0], {}).get("hbm_bytes_per_launch")
+        if os.path.exists(tpath) and args.config == "c2":          # recorded PMC passes of THIS workload, per kernel
+            rec = json.load(open(tpath))
+            traffic = rec.get("per_kernel", {}).get(kname.split("<")[0], {}).get("hbm_bytes_per_launch")
+            traffic_src = f"recorded rocprofv3 --pmc passes, profiles/conv3x3_traffic.json ({rec.get('recorded', 'round 1')})"
         out = {
             "metric": f"MCTS leaf evals/sec ({SIZE}x{SIZE}, transition + NN forward)",
             "value": round(total_evals / t_max, 1),
@@ -217,15 +360,18 @@ def main():
                        "weights": "random init, seed 0", "leaf_evals_timed": int(total_evals)},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "avg_launch_us": round(conv_ms / conv_n * 1e3, 2), "launches_timed": conv_n,
-                         "flop_per_launch": conv_flop, "convs_per_launch": cpl,
+                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "avg_launch_us": round(launch_s * 1e6, 2), "launches_timed": conv_n,
+                         "executed_mfma_flop_per_launch": executed_flop, "convs_per_launch": cpl,
                          "algorithm": {0: "direct implicit GEMM, fp32 MFMA", 1: "Winograd F(2x2,3x3), fp32 MFMA",
-                                       2: "direct implicit GEMM, bf16 MFMA on hi+lo split operands",
+                                       2: "direct implicit GEMM, bf16 MFMA on hi+lo split operands (3 products per multiply-add)",
                                        3: "Winograd F(3x3,3x3), fp32 MFMA",
                                        4: "Winograd F(3x3,3x3), fp32 MFMA (16x16x4 + 4x4x1), two 32-channel chunks per output transform"}[algo],
-                         "executed_mfma_flop_per_launch": executed_flop,
-                         "mfma_pipe_frac": round(executed_flop / (conv_ms / conv_n * 1e-3) / 1e12 / peak, 4)},
+                         "algorithmic_flop_per_launch": conv_flop,
+                         "achieved_algorithmic": round(effective, 2),
+                         "note": "achieved / frac count the flops the matrix pipe executes; achieved_algorithmic counts the "
+                                 "convolutions' own 2*M*128*1152 flops per launch, which Winograd does with fewer products"},
+            "roofline_transition": tr,
             "games": {"total": int(tot["games"]), "finished": int(tot["finished"]),
                       "black_wins": int(tot["black_wins"]), "white_wins": int(tot["white_wins"]),
                       "moves_played": int(tot["total_steps"])},

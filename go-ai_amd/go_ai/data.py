@@ -2,9 +2,16 @@
 
 Same names, argument meaning and return shapes as the reference.  Of the replay half
 (data.py:63-105) the in-memory conversions are here (symmetries, state+action planes, replay ->
-events -> numpy batches); the pickle files and the MPI sampling (data.py:108-182) are storage and
-out of this build's scope.
+events -> numpy batches) and so is the disk replay (data.py:108-182): one pickle of a Trajectory
+collection, rank-serialised appends, balanced win / non-win sampling.  The reference passes an
+mpi4py communicator; here `comm` is anything with Get_rank / Get_size / Barrier -- `SoloComm()`
+(one process) or `TorchComm()` over an initialised torch.distributed group (gloo on CPU, RCCL on GPUs).
 """
+import collections
+import os
+import pickle
+import random
+
 import numpy as np
 
 from .env import GoGame, GoVars, context  # noqa: F401  (GoGame / GoVars are re-exported like the reference's)
@@ -90,3 +97,91 @@ def events_to_numpy(events):
     wins = np.array(list(cols[5]), dtype=int)
     pis = np.array(list(cols[6]), dtype=np.float32)
     return states, actions, rewards, next_states, terminals, wins, pis
+
+
+# ---- disk replay (/root/reference/go_ai/data.py:108-182) ---------------------------------------
+class SoloComm:
+    """Single-process stand-in for the reference's MPI communicator."""
+
+    def Get_rank(self):
+        return 0
+
+    def Get_size(self):
+        return 1
+
+    def Barrier(self):
+        pass
+
+
+class TorchComm:
+    """The communicator calls the replay code needs, over the default torch.distributed group
+    (one process per GPU, as bench.py runs)."""
+
+    def Get_rank(self):
+        import torch.distributed as dist
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+    def Get_size(self):
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def Barrier(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+
+
+def load_replay(replay_path):
+    """The Trajectory collection this package wrote to `replay_path` (data.py:108-117)."""
+    with open(replay_path, 'rb') as f:
+        return pickle.load(f)
+
+
+def mpi_sample_eventdata(comm, replay_path, batches, batchsize):
+    """Every rank, one at a time, loads the replay and draws min(batchsize * batches / 2, n) events
+    from the games black won and as many from the others (n = the smaller pool), shuffles them and
+    splits the columns into batches (data.py:120-159).  Returns (batches, number of games on disk)."""
+    comm = comm if comm is not None else SoloComm()
+    rank, sample_data, replay_len = comm.Get_rank(), None, None
+    for worker in range(comm.Get_size()):
+        if rank == worker:
+            replay = load_replay(replay_path)
+            replay_len = len(replay)
+            black_wins = replay_to_events([t for t in replay if t.get_winner() == 1])
+            black_nonwins = replay_to_events([t for t in replay if t.get_winner() != 1])
+            sample_size = min(batchsize * batches // 2, len(black_wins), len(black_nonwins))
+            sample_data = random.sample(black_wins, sample_size) + random.sample(black_nonwins, sample_size)
+            del replay
+        comm.Barrier()
+    random.shuffle(sample_data)
+    columns = events_to_numpy(sample_data)
+    sample_size = len(columns[0])
+    assert all(len(col) == sample_size for col in columns)
+    splits = max(sample_size // batchsize, 1)
+    batched = list(zip(*[np.array_split(col, splits) for col in columns]))
+    return batched, replay_len
+
+
+def mpi_disk_append_replay(comm, args, replays):
+    """Ranks take turns extending the collection at args.replay_path (data.py:162-174); a deque
+    written by reset_replay keeps its maxlen, so old games fall out."""
+    comm = comm if comm is not None else SoloComm()
+    rank = comm.Get_rank()
+    for worker in range(comm.Get_size()):
+        if rank == worker:
+            if os.path.exists(args.replay_path):
+                all_replays = load_replay(args.replay_path)
+                all_replays.extend(replays)
+            else:
+                all_replays = replays
+            with open(args.replay_path, 'wb') as f:
+                pickle.dump(all_replays, f)
+        comm.Barrier()
+
+
+def reset_replay(args):
+    """An empty deque(maxlen=args.replaysize) at args.replay_path (data.py:177-182)."""
+    if os.path.exists(args.replay_path):
+        os.remove(args.replay_path)
+    with open(args.replay_path, 'wb') as f:
+        pickle.dump(collections.deque(maxlen=args.replaysize), f)

@@ -56,11 +56,23 @@ class Context:
         self._stream = stream
         _hip.check(_hip.lib.goai_ctx_set_stream(self._h, ctypes.c_void_p(stream.cuda_stream)))
 
+    def _bind(self):
+        """Every call enqueues on torch's CURRENT stream of this device: the tensors a call allocates,
+        the copies it makes and its kernels are then ordered on one stream, and the caching allocator
+        never hands a block back while a kernel of this context still reads it.  When the current stream
+        differs from the one the context last used (a `with torch.cuda.stream(...)` block), the old
+        stream is drained first, so the context's own device state (trees, activations) stays ordered."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != self._stream.cuda_stream:
+            self._stream.synchronize()
+            self.set_stream(cur)
+
     def sync(self):
         _hip.check(_hip.lib.goai_ctx_sync(self._h))
 
     # ---- Go rules ------------------------------------------------------------------
     def transition(self, states, actions, canonical=True):
+        self._bind()
         st = _dev_u8_states(states, self.device)
         n = st.shape[0]
         acts = torch.as_tensor(np.asarray(actions) if not torch.is_tensor(actions) else actions)
@@ -72,6 +84,7 @@ class Context:
         return out, status
 
     def children(self, states, canonical=True):
+        self._bind()
         st = _dev_u8_states(states, self.device)
         n = st.shape[0]
         kids = torch.empty((n, self.A, NUM_CHNLS, self.size, self.size), dtype=torch.uint8, device=self.device)
@@ -82,6 +95,7 @@ class Context:
         return kids, valid, win
 
     def score(self, states):
+        self._bind()
         st = _dev_u8_states(states, self.device)
         n = st.shape[0]
         outs = [torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(4)]
@@ -89,6 +103,7 @@ class Context:
         return tuple(outs)   # black_area, white_area, ended, winner
 
     def liberties(self, states):
+        self._bind()
         st = _dev_u8_states(states, self.device)
         n = st.shape[0]
         b, w = [torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(2)]
@@ -102,6 +117,7 @@ class Context:
     DTYPE_F32, DTYPE_BF16X3 = 0, 1
 
     def nn_init(self, net_kind, n_blocks=3, max_batch=1024, dtype=0):
+        self._bind()
         self.net_kind = int(net_kind)
         _hip.check(_hip.lib.goai_nn_init(self._h, self.net_kind, int(n_blocks), int(max_batch), int(dtype)))
 
@@ -123,6 +139,7 @@ class Context:
 
     def load_weights(self, state_dict):
         """state_dict: mapping of the reference's keys to float tensors / arrays (host)."""
+        self._bind()
         names, arrays = [], []
         for k, v in state_dict.items():
             a = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
@@ -137,6 +154,7 @@ class Context:
         _hip.check(_hip.lib.goai_load_weights(self._h, c_names, c_ptrs, c_numels, n))
 
     def nn_forward(self, states, mode=0, want_pi=True):
+        self._bind()
         st = _dev_u8_states(states, self.device)
         n = st.shape[0]
         want_pi = want_pi and self.net_kind == self.NET_AC
@@ -151,6 +169,7 @@ class Context:
         """goai_nn_forward_static: the forward of `states` (a uint8 DEVICE tensor) into the caller's
         `pi` ([n, A] float32 or None) and `val` ([n, 1] float32) without any allocation: the
         activations live in the library's static device array (n * size**2 <= NN_STATIC_MAX_CELLS)."""
+        self._bind()
         assert states.is_cuda and states.dtype == torch.uint8 and states.is_contiguous()
         n = states.shape[0]
         _hip.check(_hip.lib.goai_nn_forward_static(self._h, _hip.ptr(states), _hip.ptr(pi), _hip.ptr(val), n, int(mode)))
@@ -159,15 +178,18 @@ class Context:
     SEARCH_AC, SEARCH_Q = 0, 1
 
     def mcts_init(self, n_games, max_sims, mode=0):
+        self._bind()
         _hip.check(_hip.lib.goai_mcts_init(self._h, int(n_games), int(max_sims), int(mode)))
         self.n_games, self.max_sims, self.search_mode = int(n_games), int(max_sims), int(mode)
 
     def mcts_reset(self, root_states):
+        self._bind()
         st = _dev_u8_states(root_states, self.device)
         assert self.n_games == 0 or st.shape == (self.n_games, NUM_CHNLS, self.size, self.size), st.shape
         _hip.check(_hip.lib.goai_mcts_reset(self._h, _hip.ptr(st)))
 
     def mcts_select(self, want_leaves=True):
+        self._bind()
         leaves = None
         if want_leaves:
             leaves = torch.empty((self.n_games, NUM_CHNLS, self.size, self.size), dtype=torch.uint8,
@@ -176,6 +198,7 @@ class Context:
         return leaves
 
     def mcts_backup(self, val_logits, pi_logits=None, prior=None, logits_are_raw=False):
+        self._bind()
         def dev32(x):
             if x is None:
                 return None
@@ -188,6 +211,7 @@ class Context:
 
     def mcts_expand(self, want_children=True):
         """Q mode: make_children of every selected leaf -> (children [G,A,6,s,s], valid [G,A])."""
+        self._bind()
         kids = valid = None
         if want_children:
             kids = torch.empty((self.n_games, self.A, NUM_CHNLS, self.size, self.size), dtype=torch.uint8,
@@ -197,28 +221,34 @@ class Context:
         return kids, valid
 
     def mcts_backup_q(self, leaf_val, child_vals, vals_are_raw=False):
+        self._bind()
         lv = torch.as_tensor(leaf_val).to(self.device, dtype=torch.float64).contiguous()
         cv = torch.as_tensor(child_vals).to(self.device, dtype=torch.float64).contiguous()
         assert lv.numel() == self.n_games and cv.numel() == self.n_games * self.A
         _hip.check(_hip.lib.goai_mcts_backup_q(self._h, _hip.ptr(lv), _hip.ptr(cv), int(bool(vals_are_raw))))
 
     def mcts_child_values(self):
+        self._bind()
         out = torch.empty((self.n_games, self.A), dtype=torch.float64, device=self.device)
         _hip.check(_hip.lib.goai_mcts_child_values(self._h, _hip.ptr(out)))
         return out
 
     def mcts_policy_value(self, temp=1.0, from_values=False):
+        self._bind()
         pi = torch.empty((self.n_games, self.A), dtype=torch.float64, device=self.device)
         _hip.check(_hip.lib.goai_mcts_policy_value(self._h, float(temp), int(bool(from_values)), _hip.ptr(pi)))
         return pi
 
     def mcts_run(self, n_sims):
+        self._bind()
         _hip.check(_hip.lib.goai_mcts_run(self._h, int(n_sims)))
 
     def mcts_steps(self, n_steps):
+        self._bind()
         _hip.check(_hip.lib.goai_mcts_steps(self._h, int(n_steps)))
 
     def mcts_readout(self):
+        self._bind()
         visits = torch.empty((self.n_games, self.A), dtype=torch.int32, device=self.device)
         prior = torch.empty((self.n_games, self.A), dtype=torch.float64, device=self.device)
         root_visits = torch.empty(self.n_games, dtype=torch.int32, device=self.device)
@@ -226,26 +256,31 @@ class Context:
         return visits, prior, root_visits
 
     def mcts_policy(self, temp=1.0):
+        self._bind()
         pi = torch.empty((self.n_games, self.A), dtype=torch.float64, device=self.device)
         _hip.check(_hip.lib.goai_mcts_policy(self._h, float(temp), _hip.ptr(pi)))
         return pi
 
     def uniform_policy(self, allow_pass=True):
+        self._bind()
         pi = torch.empty((self.n_games, self.A), dtype=torch.float64, device=self.device)
         _hip.check(_hip.lib.goai_uniform_policy(self._h, int(bool(allow_pass)), _hip.ptr(pi)))
         return pi
 
     def sample_actions(self, pi, seed, step, game_id_offset=0):
+        self._bind()
         actions = torch.empty(self.n_games, dtype=torch.int32, device=self.device)
         _hip.check(_hip.lib.goai_sample_actions(self._h, _hip.ptr(pi), int(seed), int(step), int(game_id_offset),
                                                 _hip.ptr(actions)))
         return actions
 
     def mcts_advance(self, actions):
+        self._bind()
         acts = torch.as_tensor(actions).to(self.device, dtype=torch.int32).contiguous()
         _hip.check(_hip.lib.goai_mcts_advance(self._h, _hip.ptr(acts)))
 
     def mcts_roots(self):
+        self._bind()
         states = torch.empty((self.n_games, NUM_CHNLS, self.size, self.size), dtype=torch.uint8, device=self.device)
         turn, moves, result = [torch.empty(self.n_games, dtype=torch.int32, device=self.device) for _ in range(3)]
         _hip.check(_hip.lib.goai_mcts_roots(self._h, _hip.ptr(states), _hip.ptr(turn), _hip.ptr(moves),
@@ -253,6 +288,7 @@ class Context:
         return states, turn, moves, result
 
     def mcts_counters(self):
+        self._bind()
         out = (ctypes.c_int64 * 4)()
         _hip.check(_hip.lib.goai_mcts_counters(self._h, out))
         return dict(leaf_evals=out[0], transitions=out[1], errors=out[2], forwards=out[3])
@@ -262,6 +298,7 @@ class Context:
         _hip.check(_hip.lib.goai_profile_enable(self._h, int(bool(on))))
 
     def profile_read(self):
+        self._bind()
         ms, n = ctypes.c_double(), ctypes.c_int64()
         _hip.check(_hip.lib.goai_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value

@@ -18,6 +18,9 @@ class Trajectory:
     # /root/reference/go_ai/game.py:6-52
     def __init__(self):
         self.states, self.actions, self.rewards, self.children, self.pis = [], [], [], [], []
+        # side to move of every event (0 black, 1 white) when the recorder knows it; None = the reference's
+        # assumption that a game starts with black and the colours alternate (game.py:15-24)
+        self.movers = None
 
     def add_event(self, state, action, reward, children, pi):
         self.states.append(state)
@@ -35,8 +38,8 @@ class Trajectory:
     def get_events(self):
         black_won, n, events = self.get_winner(), len(self), []
         for i, (s, a, r, c, pi) in enumerate(zip(self.states, self.actions, self.rewards, self.children, self.pis)):
-            won = black_won if i % 2 == 0 else -black_won
-            events.append((s, a, r, c, i == n - 1, won, pi))
+            white = self.movers[i] if self.movers is not None else i % 2
+            events.append((s, a, r, c, i == n - 1, -black_won if white else black_won, pi))
         return events
 
     def __len__(self):
@@ -174,13 +177,14 @@ class BatchedSelfPlay:
             pi = c.mcts_policy(self.temp) if self.search == "ac" else c.mcts_policy_value(self.temp, self.mcts == 0)
             if self._rec is not None:
                 states, turn, _, result = c.mcts_roots()
-                rec.append((states, turn, result, pi))
             acts = c.sample_actions(pi, self.seed, self.move_index, off)
             c.mcts_advance(acts)
+            if self._rec is not None:
+                # copied to the host on the group's own stream (.cpu() waits for that stream only)
+                rec.append(tuple(t.cpu() for t in (states, turn, result, pi, acts)))
             out.append((pi, acts))
         if self._rec is not None:
-            self._rec.append(tuple(torch.cat([r[i] for r in rec]).cpu() for i in range(4))
-                             + (torch.cat([a for _, a in out]).cpu(),))
+            self._rec.append(tuple(torch.cat([r[i] for r in rec]) for i in range(5)))
         self.move_index += 1
         return out
 
@@ -198,15 +202,17 @@ class BatchedSelfPlay:
         finished are dropped.  `won` of an event is from the mover's point of view; games here may
         start with white to move, so use `trajectory_events` (below) rather than index parity."""
         assert self._rec is not None, "call record() before playing"
-        final = torch.cat([c.mcts_roots()[3] for c, _ in self._each()]).cpu().numpy()
+        final = torch.cat([c.mcts_roots()[3].cpu() for c, _ in self._each()]).numpy()
+        self.sync()
         trajs = [Trajectory() for _ in range(self.n_games)]
         movers = [[] for _ in range(self.n_games)]
-        c0 = self.ctx
+        c0, stream0, _ = self.groups[0]
         for states, turn, result, pi, acts in self._rec:
             live = (result == 2).nonzero().flatten()
             for lo in range(0, len(live), children_batch):
                 idx = live[lo:lo + children_batch]
-                kids = c0.children(states[idx].to(c0.device), canonical=True)[0].cpu().numpy()
+                with torch.cuda.stream(stream0):
+                    kids = c0.children(states[idx].to(c0.device), canonical=True)[0].cpu().numpy()
                 for j, g in enumerate(idx.tolist()):
                     trajs[g].add_event(states[g].numpy().astype(np.float64), int(acts[g]), 0.0,
                                        kids[j].astype(np.float64), pi[g].numpy())
@@ -241,6 +247,42 @@ class BatchedSelfPlay:
         return dict(games=self.n_games, finished=int((result != 2).sum()), black_wins=int((result == 1).sum()),
                     white_wins=int((result == -1).sum()), total_steps=int(moves.sum()), **self.counters())
 
+    def profile_transition(self, n_boards=65536, iters=20):
+        """Time goai_transition (k_transition: GoGame.next_state) over n_boards boards -- the games' current
+        positions, repeated, each with a uniformly drawn legal non-pass move -- with HIP events on the
+        launch stream.  Returns the `roofline` object of the transition side: algorithmic bytes are
+        6P read + 6P written per board against the HBM peak."""
+        from . import _hip
+        c, stream, off = self.groups[0]
+        P = self.size * self.size
+        with torch.cuda.stream(stream):
+            states = c.mcts_roots()[0]
+            acts = c.sample_actions(c.uniform_policy(allow_pass=False), self.seed ^ 0x7a, 0, off)
+            reps = -(-n_boards // c.n_games)
+            st = states.repeat(reps, 1, 1, 1)[:n_boards].contiguous()
+            ac = acts.repeat(reps)[:n_boards].contiguous()
+            out, status = torch.empty_like(st), torch.empty(n_boards, dtype=torch.int32, device=c.device)
+
+            def call():
+                _hip.check(_hip.lib.goai_transition(c._h, _hip.ptr(st), _hip.ptr(ac), 1, _hip.ptr(out), _hip.ptr(status),
+                                                    n_boards))
+            call()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(iters):
+                call()
+            e1.record(stream)
+            e1.synchronize()
+            sec = e0.elapsed_time(e1) * 1e-3 / iters
+            legal = float((status == 0).float().mean())
+        nbytes = n_boards * 12 * P
+        return {"bound": "hbm", "kernel": f"k_transition<{self.size}>", "achieved": round(nbytes / sec / 1e9, 1),
+                "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / sec / 8e12, 4), "traffic": None,
+                "avg_launch_us": round(sec * 1e6, 2), "launches_timed": iters, "boards_per_launch": n_boards,
+                "algorithmic_bytes_per_board": 12 * P, "boards_per_s": round(n_boards / sec, 1), "legal_fraction": round(legal, 4),
+                "note": "one board per 64-lane wavefront, board in LDS: bound by the flood fill's dependent LDS round "
+                        "trips, not by HBM (DESIGN.md section 3)"}
+
     def profile_conv(self):
         """Time every conv3x3 launch of one more move with HIP events on the launch streams."""
         for c, _ in self._each():
@@ -258,11 +300,7 @@ from .sharding import STAT_FIELDS, gather_stats, reduce_stats, shard_games  # no
 
 
 def trajectory_events(traj):
-    """`Trajectory.get_events()` with the mover taken from the recorded side to move instead of the
-    event index (the reference's games always start with black, game.py:15-24)."""
-    black_won, n, events = traj.get_winner(), len(traj), []
-    movers = getattr(traj, "movers", None)
-    for i, (s, a, r, c, pi) in enumerate(zip(traj.states, traj.actions, traj.rewards, traj.children, traj.pis)):
-        white = movers[i] if movers is not None else i % 2
-        events.append((s, a, r, c, i == n - 1, -black_won if white else black_won, pi))
-    return events
+    """`Trajectory.get_events()`: `won` is from the mover's point of view, the mover taken from the
+    recorded side to move (`traj.movers`) where the recorder knows it -- batched games may start with
+    white to move -- else from the event index as in the reference (game.py:15-24)."""
+    return traj.get_events()

@@ -49,3 +49,30 @@ def test_shards_cover_all_games():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts the two ranks itself as a child
+    torch.distributed.run (as the reference's multi_proc_play starts its own workers,
+    /root/reference/go_ai/utils.py:211-232) and relays rank 0's line; here with the gloo stub body
+    (rendezvous, game sharding, barriers, gather) so that it runs without a GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                           "--backend", "gloo", "--games", "100"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, env=env, timeout=300)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["games_total"] == 200
+    assert out["leaf_evals"] == 200 * 82 * 3
+
+
+def test_bench_rejects_a_world_size_that_differs_from_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo"],
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=120)
+    assert proc.returncode != 0 and "started 2 ranks" in proc.stderr

@@ -210,6 +210,38 @@ def test_batched_selfplay_trajectories_replay_on_the_oracle():
         assert all(e[5] == (-t.get_winner() if m else t.get_winner()) for e, m in zip(ev, t.movers))
 
 
+def test_stream_groups_do_not_change_recorded_trajectories():
+    """groups=2 runs two game groups on their own HIP streams (contexts follow torch's current
+    stream, engine.Context._bind); records and trajectories must equal the single-stream run."""
+    from go_ai.game import BatchedSelfPlay
+    runs = []
+    for groups in (1, 2):
+        sp = BatchedSelfPlay(5, 12, 4, seed=11, groups=groups)
+        sp.randomize_starts(6)
+        sp.record()
+        sp.play(8)
+        runs.append(sp.trajectories(children_batch=5))
+    for a, b in zip(*runs):
+        assert len(a) == len(b) and a.get_winner() == b.get_winner() and a.movers == b.movers
+        assert a.actions == b.actions
+        assert all(np.array_equal(x, y) for x, y in zip(a.states, b.states))
+        assert all(np.array_equal(x, y) for x, y in zip(a.pis, b.pis))
+        assert all(np.array_equal(x, y) for x, y in zip(a.children, b.children))
+    # a context follows the stream it is called under
+    import torch
+    from go_ai.engine import Context
+    c = Context(5)
+    side = torch.cuda.Stream()
+    st = np.zeros((3, 6, 5, 5), np.uint8)
+    with torch.cuda.stream(side):
+        out, status = c.transition(st, [0, 1, 25])
+        assert c._stream.cuda_stream == side.cuda_stream
+    out2, status2 = c.transition(st, [0, 1, 25])
+    assert c._stream.cuda_stream == torch.cuda.current_stream().cuda_stream
+    assert torch.equal(out, out2) and torch.equal(status, status2)
+    c.close()
+
+
 def test_q_helpers_and_replay_conversions_match_oracle():
     """search.qs_from_valfunc / batchqs_from_valfunc / batch_greedy_pi / batch_temperate_pi
     (/root/reference/go_ai/search/__init__.py:13-61,90-97) and data.replay_to_events /
