@@ -234,6 +234,8 @@ def main():
                     help="arithmetic of the trunk convolutions: exact fp32 MFMA (default, the reference's precision) "
                          "or split-operand bf16 MFMA (fp32-grade results, see DESIGN.md)")
     ap.add_argument("--groups", type=int, default=1, help="independent game groups on separate HIP streams")
+    ap.add_argument("--no-refill", action="store_true",
+                    help="leave the slot of a finished game idle instead of starting the next game in it")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: CPU rehearsal of the N-rank launch / rendezvous / gather path with a stub body (no GPU)")
     args = ap.parse_args()
@@ -274,7 +276,7 @@ def main():
     n_games = args.games or cfg["games"]
     sp = BatchedSelfPlay(SIZE, n_games, SIMS, temp=1.0, device=local_rank, n_blocks=LAYERS, seed=1234,
                          game_id_offset=rank * n_games, groups=args.groups, search=cfg["search"],
-                         dtype=1 if args.dtype == "bf16x3" else 0)
+                         dtype=1 if args.dtype == "bf16x3" else 0, refill=not args.no_refill)
     sp.randomize_starts(cfg["random_moves"])
     sp.play(args.warmup)
     cnt0 = sp.counters()
@@ -357,6 +359,7 @@ def main():
                                    f"({SIMS + 1} leaf evals per game)",
                        "board": SIZE, "mcts": SIMS, "games_per_gpu": n_games, "parallelism": f"games sharded x{world}",
                        "stream_groups_per_gpu": len(sp.groups),
+                       "finished_games": "slot starts the next game from the empty board" if not args.no_refill else "slot idles",
                        "weights": "random init, seed 0", "leaf_evals_timed": int(total_evals)},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",

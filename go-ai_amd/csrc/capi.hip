@@ -274,6 +274,30 @@ int goai_mcts_advance(goai_ctx* ctx, const int32_t* actions)
     return mcts_advance(ctx, actions);
 }
 
+int goai_mcts_set_refill(goai_ctx* ctx, int on)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(ctx->tree.n_games > 0, "call goai_mcts_init first");
+    ctx->tree.refill = on != 0;
+    return GOAI_OK;
+}
+
+int goai_mcts_game_stats(goai_ctx* ctx, int64_t* stats_host)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(ctx->tree.steps_since_reset >= 0 && stats_host, "call goai_mcts_init and goai_mcts_reset first / NULL output");
+    GOAI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const size_t G = (size_t)ctx->tree.n_games;
+    std::vector<long long> slots(4 * G);
+    GOAI_HIP_CHECK(hipMemcpy(slots.data(), ctx->tree.fin, slots.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; k++) {
+        int64_t sum = 0;
+        for (size_t g = 0; g < G; g++) sum += slots[k * G + g];
+        stats_host[k] = sum;
+    }
+    return GOAI_OK;
+}
+
 int goai_mcts_roots(goai_ctx* ctx, uint8_t* states, int32_t* turn, int32_t* moves, int32_t* result)
 {
     CTX_ENTER(ctx);

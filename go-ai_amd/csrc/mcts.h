@@ -41,6 +41,9 @@ struct Tree {
     int32_t* turn = nullptr;     // absolute colour to move at the root (0 black, 1 white)
     int32_t* moves = nullptr;    // moves played so far in the game
     int32_t* result = nullptr;   // 2 = running, else black's result {-1,0,1} once finished
+    int32_t* episode = nullptr;  // games this slot has finished and replaced by a fresh one (refill mode)
+    long long* fin = nullptr;    // [4][G] totals over the games a slot finished: count, black wins, white wins, moves
+    int refill = 0;              // goai_mcts_set_refill: a finished game's slot restarts from the empty board
     // NN hand-off
     uint8_t* leaf_planes = nullptr;   // [G][6][P]
     float* pi_logits = nullptr;       // [G][A]

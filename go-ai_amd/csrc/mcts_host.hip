@@ -45,7 +45,7 @@ int mcts_init(goai_ctx* c, int n_games, int max_sims, int mode)
     AL(accR, N * 8); AL(accT, N * 8);
     AL(prior, R * A); AL(child, R * A); AL(crow, R * A); AL(cN, R * A); AL(cQ, R * A);
     AL(nnodes, G); AL(nrows, G); AL(leaf, G); AL(depth, G); AL(path, R);
-    AL(turn, G); AL(moves, G); AL(result, G);
+    AL(turn, G); AL(moves, G); AL(result, G); AL(episode, G); AL(fin, 4 * G);
     AL(leaf_planes, G * 6 * P); AL(pi_logits, G * A); AL(val_logits, G);
     AL(sqrt_tab, (size_t)max_sims + 2);
     AL(counters, 4 * G);
@@ -63,6 +63,8 @@ int mcts_init(goai_ctx* c, int n_games, int max_sims, int mode)
     GOAI_HIP_CHECK(hipMemcpy(t.sqrt_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     GOAI_HIP_CHECK(hipMemset(t.counters, 0, 4 * G * sizeof(unsigned long long)));
     GOAI_HIP_CHECK(hipMemset(t.visits, 0, N * sizeof(int32_t)));
+    GOAI_HIP_CHECK(hipMemset(t.episode, 0, G * sizeof(int32_t)));
+    GOAI_HIP_CHECK(hipMemset(t.fin, 0, 4 * G * sizeof(long long)));
     t.n_games = n_games;
     t.steps_since_reset = -1;   // no roots yet
     return GOAI_OK;

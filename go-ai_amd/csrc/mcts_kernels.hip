@@ -65,6 +65,8 @@ __global__ __launch_bounds__(64) void k_mcts_reset(Tree t, const uint8_t* __rest
         t.turn[g] = player;
         t.moves[g] = 0;
         t.result[g] = (flags & FLAG_DONE) ? (player ? -sign : sign) : 2;
+        t.episode[g] = 0;
+        for (int k = 0; k < 4; k++) t.fin[(size_t)k * t.n_games + g] = 0;
     }
 }
 
@@ -392,7 +394,8 @@ __global__ __launch_bounds__(64) void k_sample(Tree t, const double* __restrict_
     if (lane_id() != 0) return;
     const double* p = pi + (size_t)g * G::A;
     uint32_t r[4];
-    const uint64_t gid = (uint64_t)(g + game_offset);
+    // global game id: the slot's id, plus (refill mode) how many games the slot has already finished
+    const uint64_t gid = (uint64_t)(g + game_offset) + ((uint64_t)(uint32_t)t.episode[g] << 32);
     philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
                   (uint32_t)(seed >> 32), r);
     const double u = (double)((((uint64_t)r[0] << 32) | r[1]) >> 11) * 0x1p-53;
@@ -431,11 +434,30 @@ __global__ __launch_bounds__(64) void k_mcts_advance(Tree t, const int32_t* __re
         if (rc != 0) {
             if (lane == 0) atomicAdd(&t.counters[(size_t)2 * t.n_games + g], 1ull);
         } else if (lane == 0) {
-            node_store<S>(t, nb, nme, nopp, ninv, pack_meta(nflags, sgn));
             const int nturn = t.turn[g] ^ 1, nmoves = t.moves[g] + 1;
-            t.turn[g] = nturn;
-            t.moves[g] = nmoves;
-            if ((nflags & FLAG_DONE) || nmoves > max_moves) t.result[g] = nturn ? -sgn : sgn;
+            const bool over = (nflags & FLAG_DONE) || nmoves > max_moves;
+            const int res = nturn ? -sgn : sgn;                 // black's result (game.py:113)
+            if (over) {
+                const size_t G = (size_t)t.n_games;
+                t.fin[0 * G + g] += 1;
+                t.fin[1 * G + g] += res == 1;
+                t.fin[2 * G + g] += res == -1;
+                t.fin[3 * G + g] += nmoves;
+            }
+            if (over && t.refill) {
+                // the slot starts its next game: go_env.reset() (game.py:139-140) = the empty board, black to move
+#pragma unroll
+                for (int k = 0; k < G::K; k++) { nme[k] = 0; nopp[k] = 0; ninv[k] = 0; }
+                node_store<S>(t, nb, nme, nopp, ninv, pack_meta(0, 0));
+                t.turn[g] = 0;
+                t.moves[g] = 0;
+                t.episode[g] += 1;
+            } else {
+                node_store<S>(t, nb, nme, nopp, ninv, pack_meta(nflags, sgn));
+                t.turn[g] = nturn;
+                t.moves[g] = nmoves;
+                if (over) t.result[g] = res;
+            }
         }
     }
     if (lane == 0) {

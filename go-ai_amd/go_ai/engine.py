@@ -279,6 +279,17 @@ class Context:
         acts = torch.as_tensor(actions).to(self.device, dtype=torch.int32).contiguous()
         _hip.check(_hip.lib.goai_mcts_advance(self._h, _hip.ptr(acts)))
 
+    def mcts_set_refill(self, on=True):
+        """Finished games are replaced by fresh ones (empty board) in their slot by mcts_advance."""
+        _hip.check(_hip.lib.goai_mcts_set_refill(self._h, int(bool(on))))
+
+    def mcts_game_stats(self):
+        """Totals over the games finished since the last reset: finished, black_wins, white_wins, moves."""
+        self._bind()
+        out = (ctypes.c_int64 * 4)()
+        _hip.check(_hip.lib.goai_mcts_game_stats(self._h, out))
+        return dict(finished=out[0], black_wins=out[1], white_wins=out[2], finished_moves=out[3])
+
     def mcts_roots(self):
         self._bind()
         states = torch.empty((self.n_games, NUM_CHNLS, self.size, self.size), dtype=torch.uint8, device=self.device)

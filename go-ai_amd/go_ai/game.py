@@ -93,10 +93,12 @@ class BatchedSelfPlay:
     them (the groups never exchange data; results do not depend on the grouping)."""
 
     def __init__(self, size, n_games, mcts, temp=1.0, state_dict=None, device=0, n_blocks=3, seed=1234,
-                 game_id_offset=0, groups=1, search="ac", nn_batch=32768, dtype=Context.DTYPE_F32):
+                 game_id_offset=0, groups=1, search="ac", nn_batch=32768, dtype=Context.DTYPE_F32, refill=False):
         """search = "ac": actor-critic search (ActorCritic policy); "q": Q-value search with the
         value network (Value policy): every leaf expansion evaluates the leaf and all its valid
-        children, in slices of at most nn_batch states."""
+        children, in slices of at most nn_batch states.  refill=True: a slot whose game ends starts a
+        new one from the empty board at once (play_games' episode loop, game.py:139-145, per slot), so
+        the batch stays full however long the run; stats() counts every finished game either way."""
         from .models import random_state_dict
         from .sharding import shard_games
         assert search in ("ac", "q")
@@ -118,6 +120,7 @@ class BatchedSelfPlay:
                 c.nn_init(Context.NET_VAL, n_blocks, min(nn_batch, (hi - lo) * (size * size + 2)), dtype=dtype)
             c.load_weights(sd)
             c.mcts_init(hi - lo, mcts, Context.SEARCH_AC if search == "ac" else Context.SEARCH_Q)
+            c.mcts_set_refill(refill)
             self.groups.append((c, stream, game_id_offset + lo))
         self.ctx = self.groups[0][0]
         self.move_index = 0
@@ -237,15 +240,17 @@ class BatchedSelfPlay:
         return tot
 
     def stats(self):
-        res, mv = [], []
+        """games = slots; finished / black_wins / white_wins = games completed since the last reset (in
+        refill mode a slot completes several); total_steps = moves played in them and in the running games."""
+        tot = dict(finished=0, black_wins=0, white_wins=0, finished_moves=0)
+        running_moves = 0
         for c, _ in self._each():
-            _, turn, moves, result = [t.cpu().numpy() for t in c.mcts_roots()]
-            res.append(result)
-            mv.append(moves)
-        import numpy as _np
-        result, moves = _np.concatenate(res), _np.concatenate(mv)
-        return dict(games=self.n_games, finished=int((result != 2).sum()), black_wins=int((result == 1).sum()),
-                    white_wins=int((result == -1).sum()), total_steps=int(moves.sum()), **self.counters())
+            _, _, moves, result = [t.cpu().numpy() for t in c.mcts_roots()]
+            running_moves += int(moves[result == 2].sum())
+            for k, v in c.mcts_game_stats().items():
+                tot[k] += v
+        return dict(games=self.n_games, finished=tot["finished"], black_wins=tot["black_wins"],
+                    white_wins=tot["white_wins"], total_steps=tot["finished_moves"] + running_moves, **self.counters())
 
     def profile_transition(self, n_boards=65536, iters=20):
         """Time goai_transition (k_transition: GoGame.next_state) over n_boards boards -- the games' current

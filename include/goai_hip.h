@@ -252,6 +252,17 @@ int goai_sample_actions(goai_ctx* ctx, const double* pi, uint64_t seed, uint64_t
  * mct.py:52-53).  A game ends after two passes or more than 2*S*S moves (game.py:74,98). */
 int goai_mcts_advance(goai_ctx* ctx, const int32_t* actions);
 
+/* Slot refill for long self-play runs (play_games' loop over episodes, /root/reference/go_ai/game.py:139-145,
+ * with every slot of the batch as one sequential player): when on, goai_mcts_advance replaces a game that just
+ * ended by a fresh one -- go_env.reset(): the empty board, black to move -- in the same slot, so the batch
+ * never carries finished games.  The slot's Philox stream moves on to game id + 2^32 * (games finished in the slot). */
+int goai_mcts_set_refill(goai_ctx* ctx, int on);
+
+/* Totals over all games finished since the last goai_mcts_reset, refilled or not (the sums play_games
+ * returns and mpi_play all-reduces, game.py:147-149, utils.py:201-204): stats_host[0] games finished,
+ * [1] black wins, [2] white wins, [3] moves played in them.  Synchronises the stream. */
+int goai_mcts_game_stats(goai_ctx* ctx, int64_t* stats_host);
+
 /* Current roots: canonical states [n_games][6][S][S], side to move (0 black / 1 white), moves
  * played, result (2 = running, else black's result in {-1,0,1}, game.py:113); any may be NULL. */
 int goai_mcts_roots(goai_ctx* ctx, uint8_t* states, int32_t* turn, int32_t* moves, int32_t* result);

@@ -90,6 +90,35 @@ def test_batched_selfplay_runs_games_to_the_end():
     assert 0 < st["leaf_evals"] <= 64 * 7 * 52
 
 
+def test_batched_selfplay_refills_finished_slots():
+    """refill=True: a slot whose game ends starts the next one from the empty board (play_games' episode
+    loop, game.py:139-145), so every slot searches at every move; totals count every finished game and
+    do not depend on how the slots are sharded over contexts (Philox streams keyed by slot id + episode)."""
+    from go_ai.game import BatchedSelfPlay
+    n, sims, moves = 64, 6, 130
+    runs = []
+    for shards in (1, 1, 2):
+        tot = None
+        for k in range(shards):
+            m = n // shards
+            sp = BatchedSelfPlay(5, m, sims, seed=3, refill=True, game_id_offset=k * m)
+            sp.play(moves)
+            st = sp.stats()
+            states, turn, mv, result = [t.cpu().numpy() for t in sp.ctx.mcts_roots()]
+            assert (result == 2).all() and (mv <= 2 * 25).all()
+            assert st["errors"] == 0 and st["leaf_evals"] == m * (sims + 1) * moves      # no idle slot, ever
+            assert st["total_steps"] == m * moves
+            tot = st if tot is None else {k2: tot[k2] + st[k2] for k2 in st}
+        runs.append(tot)
+    assert runs[0] == runs[1] == runs[2]
+    assert runs[0]["finished"] > n and runs[0]["black_wins"] + runs[0]["white_wins"] <= runs[0]["finished"]
+    # without refill the same seeds give the same first games, and finished slots idle
+    sp = BatchedSelfPlay(5, n, sims, seed=3)
+    sp.play(moves)
+    st = sp.stats()
+    assert st["finished"] == n and st["leaf_evals"] < runs[0]["leaf_evals"]
+
+
 def test_batched_selfplay_19x19_runs_games_to_the_end():
     """BASELINE.json configs[4]'s board: k_mcts_select / backup / policy / sample / advance at S = 19
     (362 actions, six actions per lane) over whole games, to the 2 * 361 move cap (game.py:74,98); the
