@@ -47,7 +47,7 @@ def timed(fn, iters):
 
 for size in args.sizes:
     P, A = size * size, size * size + 1
-    n = args.batch if size <= 9 else args.batch // 4
+    n = args.batch
     c = Context(size)
     st = positions(c, size, n, moves=P // 2)
     stones = float((st[:, 0] | st[:, 1]).sum()) / n
