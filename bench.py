@@ -230,7 +230,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--games", type=int, default=0, help="games per GPU (default: the config's)")
-    ap.add_argument("--dtype", choices=["f32", "bf16x3"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16x3", "bf16x6"], default="f32",
                     help="arithmetic of the trunk convolutions: exact fp32 MFMA (default, the reference's precision) "
                          "or split-operand bf16 MFMA (fp32-grade results, see DESIGN.md)")
     ap.add_argument("--groups", type=int, default=1, help="independent game groups on separate HIP streams")
@@ -276,7 +276,7 @@ def main():
     n_games = args.games or cfg["games"]
     sp = BatchedSelfPlay(SIZE, n_games, SIMS, temp=1.0, device=local_rank, n_blocks=LAYERS, seed=1234,
                          game_id_offset=rank * n_games, groups=args.groups, search=cfg["search"],
-                         dtype=1 if args.dtype == "bf16x3" else 0, refill=not args.no_refill)
+                         dtype={"f32": 0, "bf16x3": 1, "bf16x6": 2}[args.dtype], refill=not args.no_refill)
     sp.randomize_starts(cfg["random_moves"])
     sp.play(args.warmup)
     cnt0 = sp.counters()
@@ -306,7 +306,8 @@ def main():
     launch_s = conv_ms / conv_n * 1e-3
     peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     algo = sp.ctx.nn_conv_algo()
-    kname = {0: "k_conv3x3", 1: "k_conv3x3_wino", 2: "k_conv3x3_bf16", 3: "k_conv3x3_wino3", 4: "k_conv3x3_wino3p"}[algo] + f"<{SIZE}>"
+    kname = {0: "k_conv3x3", 1: "k_conv3x3_wino", 2: "k_conv3x3_bf16", 3: "k_conv3x3_wino3", 4: "k_conv3x3_wino3p",
+             5: "k_conv3x3_wino3s"}[algo] + f"<{SIZE}>"
     executed_flop = conv_flop                 # flops the matrix pipe really executes per launch
     if algo == 2:
         executed_flop = 3.0 * conv_flop       # hi*hi + lo*hi + hi*lo on the bf16 pipe
@@ -317,6 +318,11 @@ def main():
         wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // (112 // t2))
         rows = 100 if SIZE in (9, 13, 19) else 112       # six 16-row tiles + one round of 4x4 blocks, or seven tiles
         executed_flop = 2.0 * wgs * rows * 16 * 128 * 128
+    elif algo == 5:
+        # Winograd F(3x3,3x3) on the bf16 pipe: 4 boards = 36 wtile rows run as three 16-column tiles, six
+        # bf16 products (three-way split operands) per transform-domain multiply-add
+        wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // 4)
+        executed_flop = 6 * 2.0 * wgs * 48 * 25 * 128 * 128 * cpl
     elif algo in (3, 4):
         # Winograd F(3x3,3x3): 25 products per 3x3 output tile; workgroups of 48 tile rows = 4 boards of 9x9
         # (5 boards once 4 per workgroup would need more than one round of CUs)
@@ -369,7 +375,9 @@ def main():
                          "algorithm": {0: "direct implicit GEMM, fp32 MFMA", 1: "Winograd F(2x2,3x3), fp32 MFMA",
                                        2: "direct implicit GEMM, bf16 MFMA on hi+lo split operands (3 products per multiply-add)",
                                        3: "Winograd F(3x3,3x3), fp32 MFMA",
-                                       4: "Winograd F(3x3,3x3), fp32 MFMA (16x16x4 + 4x4x1), two 32-channel chunks per output transform"}[algo],
+                                       4: "Winograd F(3x3,3x3), fp32 MFMA (16x16x4 + 4x4x1), two 32-channel chunks per output transform",
+                                       5: "Winograd F(3x3,3x3), bf16 MFMA 16x16x32 on operands split exactly into three bf16 parts "
+                                          "(6 products per multiply-add, fp32 accumulate, fp32 transforms): fp32-grade results"}[algo],
                          "algorithmic_flop_per_launch": conv_flop,
                          "achieved_algorithmic": round(effective, 2),
                          "note": "achieved / frac count the flops the matrix pipe executes; achieved_algorithmic counts the "

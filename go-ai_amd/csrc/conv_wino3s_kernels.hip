@@ -1,0 +1,418 @@
+// conv_wino3s_kernels.hip -- the F(3x3,3x3) trunk of conv_wino3p_kernels.hip with its 25 transform-domain
+// GEMMs on the BF16 matrix cores, every fp32 operand SPLIT INTO THREE bf16 parts (GOAI_DTYPE_BF16X6).
+//
+// Why: the fp32 MFMA runs on the vector ALUs' own multipliers (same peak, 157 TF, and no overlap with
+// vector instructions on a SIMD: tools/ubench/mfma_valu*.hip), so in conv_wino3p_kernels.hip the
+// Winograd transforms, which are vector work, add their full issue time to the products'.  The bf16
+// MFMA is separate hardware (2.5 PF dense, 16 times the fp32 rate) that runs beside vector
+// instructions.  An fp32 number is EXACTLY the sum of three bf16 numbers (3 x 8 significant bits:
+// h = top 16 bits of x, m = top 16 bits of x - h, l = x - h - m), so with U = u0 + u1 + u2 (folded
+// weights, split once on the host) and V = v0 + v1 + v2 (transformed inputs, split by the threads that
+// compute them)
+//       U V  =  u0 v0 + (u0 v1 + u1 v0) + (u0 v2 + u1 v1 + u2 v0)  +  terms below 2^-24 |U V|
+// every bf16 product is exact in the fp32 accumulator and the three dropped terms are below the
+// rounding of a single fp32 product: fp32-grade results from 6 bf16 MFMAs of K = 32 per 16x16 tile
+// (96 matrix-pipe cycles) where the fp32 path issues 8 MFMAs of K = 4 (256 cycles on the vector ALUs).
+//
+// Structure = conv_wino3p_kernels.hip (whole boards per workgroup, two 32-channel chunks per output
+// transform, the whole residual trunk in one launch, fp32 input / output transforms on the vector ALUs):
+//   [zero cell 128 B][image chunk A 41,472 B] [zero cell][image chunk B]          fp32, cell * 128 B
+//   V[2 chunks][5 q][3 parts][36 rows + zero row][32 ch] bf16                       71 KB, single-buffered
+//   Tab[36 wtiles][5 patch rows] -> five 16-bit cell addresses
+// = 157 KB.  The 36 wtile rows of 4 boards are two full 16-column MFMA tiles and a third whose other
+// 12 columns read the zero row (the bf16 pipe has cycles to spare; no 4x4 blocks here).
+// Weights: [conv][100 stages][8 waves][3 parts][64 lanes][8 bf16] -- a lane's A operand (its output
+// channel, its 8 input channels) as one 16-byte load per part.
+#include <type_traits>
+#include "go_board.h"
+#include "goai_internal.h"
+#include "nn.h"
+
+namespace goai {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int S>
+struct Wino3S {
+    static_assert(S == 9, "row mapping: 8 + 1 wtiles per board, 4 boards");
+    static constexpr int T = S / 3, T2 = T * T, P = S * S;
+    static constexpr int NBW = 4;                                  // whole boards per workgroup
+    static constexpr int WT = NBW * T2;                            // real wtiles per workgroup
+    static constexpr int MT = (WT + 15) / 16;                      // MFMA column tiles of 16 wtile rows (the last: 4 real)
+    static constexpr int VROWS = WT + 1;                           // the wtile rows + one zero row
+    static constexpr int IMG_CH_U4 = 8 + NBW * P * 8;              // 16-byte units per chunk region: zero cell + cells
+    static constexpr int V_PART_U4 = VROWS * 4;                    // one (chunk, q, part): [VROWS][32 ch] bf16 = 64 B per row
+    static constexpr int V_U4 = 2 * 5 * 3 * V_PART_U4;             // [2 chunks][5 q][3 parts]
+    static constexpr int TAB_U4 = WT * 5;                          // [wtile][a] -> 8 x u16 (5 used)
+    static constexpr int NI = (NBW * P * 8 + 511) / 512;
+    static constexpr int LDS_U4 = 2 * IMG_CH_U4 + V_U4 + TAB_U4;
+    static_assert(LDS_U4 * 16 <= 160 * 1024, "LDS budget");
+    static_assert(IMG_CH_U4 * 16 < 65536, "cell addresses and the chunk offset are 16-bit");
+};
+
+#ifdef GOAI_CONV_STAMPS
+// diagnostic build only (tools/wino3p_stamps.py): s_memrealtime (100 MHz) stamps of the SECOND convolution of
+// a launch, 32 per workgroup: 0 layer top, 1 image staged, 2 + 2r transform of row r done (r = 5 cp + p),
+// 3 + 2r its stages done, 22 epilogue done; 23 / 24 = s_memtime (shader clock) at stamps 0 / 22
+__device__ unsigned long long g_wino3s_stamps[32 * 1024];
+extern "C" int goai_debug_wino3s_stamps(unsigned long long* host_out, int n)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino3s_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#define W3S_STAMP(i) if (threadIdx.x == 0 && k == 1) { g_wino3s_stamps[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); if ((i) == 0 || (i) == 22) g_wino3s_stamps[blockIdx.x * 32 + 23 + ((i) == 22)] = __builtin_amdgcn_s_memtime(); }
+#else
+#define W3S_STAMP(i)
+#endif
+
+__device__ __forceinline__ f32x4 s_fma4(float c, f32x4 a, f32x4 b)
+{
+    return f32x4{ fmaf(c, a[0], b[0]), fmaf(c, a[1], b[1]), fmaf(c, a[2], b[2]), fmaf(c, a[3], b[3]) };
+}
+// two fp32 bit patterns whose low halves are dropped -> one word of two bf16 (a in the low half)
+__device__ __forceinline__ unsigned s_pack(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+// Same launch contract as k_conv3x3_wino3 (n_convs convolutions in a row on the same boards).
+template <int S>
+__global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, const float* resid0,
+                                                        const uint4* wt_all,
+                                                        const float* __restrict__ bias_all,
+                                                        const uint4* __restrict__ tab_g, int nboards, int n_convs)
+{
+    using W = Wino3S<S>;
+    constexpr int P = W::P, MT = W::MT;
+    __shared__ f32x4 lds[W::LDS_U4];
+    f32x4* Img = lds;                                  // two chunk regions
+    f32x4* Vs = lds + 2 * W::IMG_CH_U4;
+    uint4* Tab = reinterpret_cast<uint4*>(lds + 2 * W::IMG_CH_U4 + W::V_U4);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int b_first = blockIdx.x * W::NBW;
+    const float* in = x;
+    const float* resid = resid0;
+    float* out = y;
+
+    for (int i = tid; i < W::V_U4; i += 512) Vs[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };   // the zero rows stay zero
+    if (tid < 16) Img[(tid >> 3) * W::IMG_CH_U4 + (tid & 7)] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };   // the two zero cells
+    for (int e = tid; e < W::TAB_U4; e += 512) Tab[e] = tab_g[e];
+
+    // input-transform job of this thread: WT * 8 (wtile, channel slot) items spread evenly over the
+    // eight waves, lanes 0..LPG-1 of every 16 take one; each item is done for both chunks
+    constexpr int LPG = (W::WT * 8 + 31) / 32;
+    static_assert(LPG <= 16, "too many wtiles for one transform pass");
+    const int item = (tid >> 4) * LPG + (tid & 15);
+    const bool t_on = (tid & 15) < LPG && item < W::WT * 8;
+    const int ts = item & 7, ttw = t_on ? item >> 3 : 0;
+    // V row of a wtile: wtiles 0..7 of board b -> row 8 b + wtile (two full column tiles);
+    // wtile 8 of board b -> row 32 + b (the third tile; its columns 4..15 read the zero row).
+    const int tvrow = (ttw % W::T2 < 8) ? (ttw / W::T2) * 8 + ttw % W::T2 : 32 + ttw / W::T2;
+
+    f32x4 ireg[W::NI];
+    auto load_img_to = [&](int chunk, f32x4* reg) {
+#pragma unroll
+        for (int i = 0; i < W::NI; i++) {
+            const int idx = tid + i * 512;
+            const int cr = idx >> 3, slot = idx & 7;
+            const int board = b_first + cr / P;
+            f32x4 v = { 0.0f, 0.0f, 0.0f, 0.0f };
+            if (idx < W::NBW * P * 8 && board < nboards)
+                v = *reinterpret_cast<const f32x4*>(&in[((long)b_first * P + cr) * 128 + chunk * 32 + slot * 4]);
+            reg[i] = v;
+        }
+    };
+    auto store_img_from = [&](int region, const f32x4* reg) {
+#pragma unroll
+        for (int i = 0; i < W::NI; i++) {
+            const int idx = tid + i * 512;
+            if (idx < W::NBW * P * 8) Img[region * W::IMG_CH_U4 + 8 + idx] = reg[i];
+        }
+    };
+    auto load_img = [&](int chunk) { load_img_to(chunk, ireg); };
+    auto store_img = [&](int region) { store_img_from(region, ireg); };
+    const char* img_lane = reinterpret_cast<const char*>(Img) + ts * 16;
+    const uint4* tabrow = Tab + ttw * 5;
+    // V[c][q][tw][ts] = (Bt d B)[p][q], q = 0..4, for row p (compile-time after unrolling), chunk region c
+    auto transform = [&](int p, int c) {
+        if (!t_on) return;
+        const char* base = img_lane + c * (W::IMG_CH_U4 * 16);
+        auto patch_row = [&](int a, f32x4* d) {
+            const uint4 t = tabrow[a];
+            d[0] = *reinterpret_cast<const f32x4*>(base + (t.x & 0xffffu));
+            d[1] = *reinterpret_cast<const f32x4*>(base + (t.x >> 16));
+            d[2] = *reinterpret_cast<const f32x4*>(base + (t.y & 0xffffu));
+            d[3] = *reinterpret_cast<const f32x4*>(base + (t.y >> 16));
+            d[4] = *reinterpret_cast<const f32x4*>(base + (t.z & 0xffffu));
+        };
+        f32x4 r[5], d1[5], d2[5], d3[5];
+        patch_row(1, d1);
+        if (p != 3) patch_row(2, d2);
+        patch_row(3, d3);
+        if (p == 0) {
+            f32x4 d0[5];
+            patch_row(0, d0);
+#pragma unroll
+            for (int b = 0; b < 5; b++) r[b] = s_fma4(-2.0f, d2[b], s_fma4(2.0f, d0[b], d3[b] - d1[b]));
+        } else if (p == 1) {
+#pragma unroll
+            for (int b = 0; b < 5; b++) r[b] = s_fma4(-2.0f, d1[b], d3[b] - d2[b]);
+        } else if (p == 2) {
+#pragma unroll
+            for (int b = 0; b < 5; b++) r[b] = s_fma4(-3.0f, d2[b], s_fma4(2.0f, d1[b], d3[b]));
+        } else if (p == 3) {
+#pragma unroll
+            for (int b = 0; b < 5; b++) r[b] = d3[b] - d1[b];
+        } else {
+            f32x4 d4[5];
+            patch_row(4, d4);
+#pragma unroll
+            for (int b = 0; b < 5; b++) r[b] = s_fma4(-2.0f, d3[b], s_fma4(2.0f, d1[b], d4[b] - d2[b]));
+        }
+        // each fp32 value as three bf16 parts (exact: top 16 bits, top 16 bits of the rest, the rest), 4 channels
+        // = 8 bytes per part at [row tvrow][channel 4 ts]
+        uint2* V = reinterpret_cast<uint2*>(Vs + c * (5 * 3 * W::V_PART_U4)) + tvrow * 8 + ts;
+        auto put = [&](int q, const f32x4 v) {
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                h[e] = __float_as_uint(v[e]) & 0xffff0000u;
+                const float r1 = v[e] - __uint_as_float(h[e]);
+                m[e] = __float_as_uint(r1) & 0xffff0000u;
+                l[e] = __float_as_uint(r1 - __uint_as_float(m[e]));      // <= 8 significant bits: its low half is zero
+            }
+            uint2* dst = V + q * (3 * W::V_PART_U4 * 2);
+            dst[0] = uint2{ s_pack(h[0], h[1]), s_pack(h[2], h[3]) };
+            dst[W::V_PART_U4 * 2] = uint2{ s_pack(m[0], m[1]), s_pack(m[2], m[3]) };
+            dst[2 * W::V_PART_U4 * 2] = uint2{ s_pack(l[0], l[1]), s_pack(l[2], l[3]) };
+        };
+        put(0, s_fma4(-2.0f, r[2], s_fma4(2.0f, r[0], r[3] - r[1])));
+        put(1, s_fma4(-2.0f, r[1], r[3] - r[2]));
+        put(2, s_fma4(-3.0f, r[2], s_fma4(2.0f, r[1], r[3])));
+        put(3, r[3] - r[1]);
+        put(4, s_fma4(-2.0f, r[3], s_fma4(2.0f, r[1], r[4] - r[2])));
+    };
+
+    // weight fragments of a half-stage: the three bf16 parts of U[stage = (chunk * 5 + p) * 5 + q] in the lanes' own
+    // order (nn_host.hip): lane (li, lq) gets output channel 16 wave + li, input channels 8 lq .. 8 lq + 7 of the chunk
+    const uint4* wsrc = wt_all + wave * 192 + lane;        // [stage][wave][part][lane] x 16 B: whole lines per load
+    u32x4 wf[2][3];                                        // two half-stages of weights, used alternately
+    auto load_b = [&](int stage, u32x4* b) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(wsrc + (size_t)stage * (8 * 192));
+        b[0] = src[0];
+        b[1] = src[64];
+        b[2] = src[128];
+        // the optimiser otherwise sinks a load whose value is first used in the next loop iteration down to the
+        // loop's end, i.e. right in front of its use (wt_all is deliberately not __restrict__: loads from a
+        // noalias pointer may cross this barrier)
+        asm volatile("" ::: "memory");
+    };
+
+    f32x4 Y[3][3][MT];                               // [i][j]: output (3ty + i, 3tx + j) of the wtile
+    const int col = wave * 16 + 4 * lq;
+    // V row of this lane's column in each of the three column tiles (the B operand's "column" = a wtile row)
+    int vrow[MT];
+    vrow[0] = li;
+    vrow[1] = 16 + li;
+    vrow[2] = li < 4 ? 32 + li : W::WT;              // the zero row
+
+#pragma unroll 1
+    for (int k = 0; k < n_convs; k++) {
+    const float* bias = bias_all + k * 128;
+    load_b(0, wf[0]);
+    // k = 0: the zero fills and the table are complete; k > 0: every wave's MFMAs of the previous
+    // convolution have read V and its stores to `in` are visible to this workgroup
+    __syncthreads();
+    W3S_STAMP(0);
+    {
+        f32x4 ireg1[W::NI];                          // both chunks in flight at once: the accumulators are not live yet
+        load_img(0);
+        load_img_to(1, ireg1);
+        store_img(0);
+        store_img_from(1, ireg1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int t = 0; t < MT; t++) Y[i][j][t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    W3S_STAMP(1);
+
+#pragma unroll 1
+    for (int cp = 0; cp < 2; cp++) {
+#pragma unroll
+        for (int p = 0; p < 5; p++) {
+            const bool stage_next = (p == 4 && cp == 0);       // chunks 2, 3 replace 0, 1 behind the last transform
+            if (stage_next) load_img(2);
+            transform(p, 0);
+            transform(p, 1);
+            __syncthreads();                                   // V complete; (p == 4) the image is dead
+            W3S_STAMP(2 + 2 * (5 * cp + p));
+            if (stage_next) {
+                store_img(0);
+                load_img(3);
+            }
+            // The row's five stages as 30 tile steps (q, chunk c, column tile t), fully unrolled and software-
+            // pipelined: the three V fragments of step n + 1 are read from LDS while the six MFMAs of step n run,
+            // and the weights of half-stage h + 1 = (q, c) + 1 are requested at the top of half-stage h (two
+            // register sets, alternating: no copies, so nothing waits for a load before its data is needed).
+            auto v_read = [&](int q, int c, int t, uint4* v) {
+                const uint4* V = reinterpret_cast<const uint4*>(Vs) + ((c * 5 + q) * 3) * W::V_PART_U4 + lq + vrow[t] * 4;
+#pragma unroll
+                for (int r = 0; r < 3; r++) v[r] = V[r * W::V_PART_U4];
+            };
+            uint4 vf[2][3];                                        // (kept as plain words: a bf16 vector across a branch is re-packed element-wise)
+            v_read(0, 0, 0, vf[0]);
+#pragma unroll 1
+            for (int q = 0; q < 5; q++) {
+                f32x4 m[MT];
+#pragma unroll
+                for (int t = 0; t < MT; t++) m[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const int h = c;                                       // half-stage of this stage; its weights sit in wf[c]
+                    {
+                        // the next half-stage's weights: (q, c = 1), else (q + 1, 0), else the next row / chunk pair
+                        int nxt;
+                        if (c == 0) nxt = ((2 * cp + 1) * 5 + p) * 5 + q;
+                        else if (q < 4) nxt = ((2 * cp) * 5 + p) * 5 + q + 1;
+                        else if (p < 4) nxt = ((2 * cp) * 5 + p + 1) * 5;
+                        else nxt = (2 * (cp + 1)) * 25;
+                        load_b(nxt < 100 ? nxt : 99, wf[(h + 1) & 1]);     // unconditional: the wait counts stay exact
+                    }
+                    const bf16x8 u0 = __builtin_bit_cast(bf16x8, wf[h & 1][0]), u1 = __builtin_bit_cast(bf16x8, wf[h & 1][1]),
+                                 u2 = __builtin_bit_cast(bf16x8, wf[h & 1][2]);
+#pragma unroll
+                    for (int t = 0; t < MT; t++) {
+                        const int n = h * MT + t;                          // tile step of the row; its fragments sit in vf[n & 1]
+                        if (t + 1 < MT) v_read(q, c, t + 1, vf[(n + 1) & 1]);
+                        else if (c == 0) v_read(q, 1, 0, vf[(n + 1) & 1]);
+                        else v_read(q < 4 ? q + 1 : 4, 0, 0, vf[(n + 1) & 1]);     // (q == 4: a harmless re-read)
+                        const bf16x8 v[3] = { __builtin_bit_cast(bf16x8, vf[n & 1][0]), __builtin_bit_cast(bf16x8, vf[n & 1][1]),
+                                              __builtin_bit_cast(bf16x8, vf[n & 1][2]) };
+                        // the six products of weight up to 2^-16, smallest first
+                        m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u2, v[0], m[t], 0, 0, 0);
+                        m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[2], m[t], 0, 0, 0);
+                        m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, v[1], m[t], 0, 0, 0);
+                        m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, v[0], m[t], 0, 0, 0);
+                        m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[1], m[t], 0, 0, 0);
+                        m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[0], m[t], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);                 // keep the pipeline as written (the scheduler
+                    }                                                      // would hoist every read of the row to its top)
+                }
+                // output transform: Y[i][j] += At[i][p] * At[j][q] * M; p is unrolled (row factors at
+                // compile time, zeros skipped), q is a run-time loop (column factors as floats)
+                const float cj0 = (q < 4) ? 1.0f : 0.0f;
+                const float cj1 = (q == 1) ? 1.0f : (q == 2 ? -1.0f : (q == 3 ? 2.0f : 0.0f));
+                const float cj2 = (q == 0) ? 0.0f : (q == 3 ? 4.0f : 1.0f);
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const int ci = (i == 0) ? (p < 4 ? 1 : 0)
+                                 : (i == 1) ? (p == 1 ? 1 : (p == 2 ? -1 : (p == 3 ? 2 : 0)))
+                                            : (p == 0 ? 0 : (p == 3 ? 4 : 1));
+                    if (ci != 0) {
+                        const float f0 = (float)ci * cj0, f1 = (float)ci * cj1, f2 = (float)ci * cj2;
+#pragma unroll
+                        for (int t = 0; t < MT; t++)
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                Y[i][0][t][e] = fmaf(f0, m[t][e], Y[i][0][t][e]);
+                                Y[i][1][t][e] = fmaf(f1, m[t][e], Y[i][1][t][e]);
+                                Y[i][2][t][e] = fmaf(f2, m[t][e], Y[i][2][t][e]);
+                            }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();                                   // every wave has read this row of V
+            W3S_STAMP(3 + 2 * (5 * cp + p));
+            if (stage_next) {
+                store_img(1);
+                __syncthreads();
+            }
+        }
+    }
+
+    // epilogue.  The products are formed transposed (A operand = weights, B operand = V), so in the
+    // C/D layout of a 16x16 tile (col = lane & 15, row = 4 * (lane >> 4) + reg) a lane holds FOUR
+    // CONSECUTIVE output channels of ONE wtile: one 16-byte load / store per output cell.  Columns 0..3
+    // of the third tile are wtile 8 of the four boards.
+    // `out` may alias `resid` (the trunk's in-place convolutions), so loads and stores stay in program
+    // order; the nine residual loads of a tile are issued together, and the residual / no-residual
+    // choice is made once, not per cell (conv_wino3p_kernels.hip).
+    auto epilogue = [&](auto has_resid) {
+        constexpr bool R = decltype(has_resid)::value;
+        auto tile = [&](const f32x4 (&yv)[3][3], const f32x4 bv, long base, bool on) {
+            // base = element offset of output (0, 0) of the wtile, this lane's channels
+            if (!on) return;
+            f32x4 rv[3][3];
+            if (R) {
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) rv[i][j] = *reinterpret_cast<const f32x4*>(&resid[base + (i * S + j) * 128]);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    f32x4 v = yv[i][j] + bv;
+                    if (R) v += rv[i][j];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
+                    *reinterpret_cast<f32x4*>(&out[base + (i * S + j) * 128]) = v;
+                }
+        };
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col]);
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int w = t * 16 + li;
+            const int bl = w >> 3, wt = w & 7;
+            const long board = b_first + bl;
+            const int ty = wt / W::T, tx = wt - ty * W::T;
+            f32x4 yv[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) yv[i][j] = Y[i][j][t];
+            tile(yv, bv, (board * P + 3 * ty * S + 3 * tx) * 128 + col, board < nboards);
+        }
+        const long board2 = b_first + li;
+        f32x4 yv[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) yv[i][j] = Y[i][j][2];
+        tile(yv, bv, (board2 * P + 6 * S + 6) * 128 + col, li < 4 && board2 < nboards);   // wtile 8 = (ty, tx) = (2, 2)
+    };
+    if (resid) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
+    W3S_STAMP(22);
+    // next convolution of the launch: swap the buffers, step the weights
+    if (k & 1) { in = x; out = y; resid = resid0; } else { in = y; out = x; resid = x; }
+    wsrc += (size_t)100 * 8 * 192;
+    }
+}
+
+// wt_split: [n_convs][100 stages][8 waves][3 parts][64 lanes][8 bf16] (nn_host.hip); tab: wino3p_build_table.
+// Any number of boards (4 per workgroup, as many rounds of workgroups as it takes).
+int launch_conv3x3_wino3s(int S_rt, float* x, float* y, const float* resid0, const void* wt_split, const float* bias,
+                          const void* tab, int nboards, int n_convs, hipStream_t st)
+{
+    if (S_rt != 9 || nboards < 1) {
+        set_error("the bf16x6 F(3x3,3x3) convolution runs 9x9 boards");
+        return GOAI_ERR_ARG;
+    }
+    if (n_convs < 1 || (n_convs > 1 && ((n_convs & 1) || resid0))) {
+        set_error("a multi-convolution launch is a whole residual trunk: an even count, no outer residual");
+        return GOAI_ERR_ARG;
+    }
+    k_conv3x3_wino3s<9><<<dim3((nboards + 3) / 4), dim3(512), 0, st>>>(x, y, resid0, reinterpret_cast<const uint4*>(wt_split), bias,
+                                                                       reinterpret_cast<const uint4*>(tab), nboards, n_convs);
+    GOAI_HIP_CHECK(hipGetLastError());
+    return GOAI_OK;
+}
+
+}  // namespace goai

@@ -28,6 +28,7 @@ static int dev_alloc(goai_ctx* c, void** p, size_t bytes)
 }
 
 constexpr size_t WT_BF16_PER_CONV = (size_t)2 * 9 * 128 * 128;   // hi and lo halves
+constexpr size_t WT_SPLIT6_PER_CONV = (size_t)100 * 8 * 3 * 64 * 8;   // bf16x6: three parts of U = G g Gt, lanes' order
 
 // float -> bfloat16 bits, round to nearest even (what v_cvt_pk_bf16_f32 does on the device)
 static uint16_t bf16_rne(float f)
@@ -74,6 +75,11 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
                 prop.multiProcessorCount > 0)
                 n.n_cu = prop.multiProcessorCount;
         }
+        if (dtype == GOAI_DTYPE_BF16X6) {
+            GOAI_REQUIRE(wino3_supported(c->S), "GOAI_DTYPE_BF16X6 is implemented for 9x9 boards (F(3x3,3x3) tiles the board exactly)");
+            n.wino_mode = 3;
+            n.split6 = true;
+        }
         if (dtype == GOAI_DTYPE_F32) {
             if (algo && std::string(algo) == "wino") n.wino_mode = 2;
             else if (algo && std::string(algo) == "wino3" && wino3_supported(c->S)) n.wino_mode = 3;
@@ -96,15 +102,17 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
         n.trunk_fused = n.wino_mode == 3 && !getenv("GOAI_NO_TRUNK_FUSION");
         {
             const char* e = getenv("GOAI_WINO3_PAIRED");
-            n.wino3_paired = n.wino_mode == 3 && wino3p_supported(c->S, max_batch, n.n_cu) && !(e && e[0] == '0');
+            n.wino3_paired = n.wino_mode == 3 && !n.split6 && wino3p_supported(c->S, max_batch, n.n_cu) && !(e && e[0] == '0');
         }
-        if (n.wino3_paired) {
+        if (n.wino3_paired || n.split6) {
             std::vector<uint16_t> tab(wino3p_build_table(c->S, nullptr));
             wino3p_build_table(c->S, tab.data());
             if ((rc = dev_alloc(c, &n.wino3p_tab, tab.size() * sizeof(uint16_t)))) return rc;
             GOAI_HIP_CHECK(hipMemcpy(n.wino3p_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         }
-        if (n.wino_mode == 3) {
+        if (n.split6) {
+            if ((rc = dev_alloc(c, &n.wt_split6, (size_t)2 * layers * WT_SPLIT6_PER_CONV * sizeof(uint16_t)))) return rc;
+        } else if (n.wino_mode == 3) {
             if ((rc = dev_alloc(c, (void**)&n.wt_wino3, (size_t)2 * layers * 25 * 128 * 128 * sizeof(float)))) return rc;
             for (int i = 0; i < 2; i++) {
                 std::vector<uint16_t> tab(wino3_build_table(c->S, 4 + i, nullptr));
@@ -113,7 +121,9 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
                 GOAI_HIP_CHECK(hipMemcpy(n.wino3_tab[i], tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             }
         }
-        if (dtype == GOAI_DTYPE_BF16X3) {
+        if (n.split6) {
+            // no direct-convolution image: this context only ever runs the split F(3x3,3x3) kernel
+        } else if (dtype == GOAI_DTYPE_BF16X3) {
             if ((rc = dev_alloc(c, &n.wt_bf16, (size_t)2 * layers * WT_BF16_PER_CONV * sizeof(uint16_t)))) return rc;
         } else if ((rc = dev_alloc(c, (void**)&n.wt, (size_t)2 * layers * 9 * 128 * 128 * sizeof(float)))) return rc;
         if ((rc = dev_alloc(c, (void**)&n.bt, (size_t)2 * layers * 128 * sizeof(float)))) return rc;
@@ -232,6 +242,40 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
                                      wb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             continue;
         }
+        if (net.split6) {
+            // bf16x6: the same U = G g Gt, rounded to fp32 as for the fp32 kernels, then cut into three bf16 parts
+            // (top 16 bits, top 16 bits of the rest, the rest: exact); [stage][wave][part][lane (li, lq)][j]:
+            // output channel 16 wave + li, input channel 32 chunk + 8 lq + j -- the lanes' MFMA A operands
+            static const double G3[5][3] = { { 0.5, 0, 0 }, { -0.5, -0.5, -0.5 }, { -1.0 / 6, 1.0 / 6, -1.0 / 6 },
+                                             { 1.0 / 6, 1.0 / 3, 2.0 / 3 }, { 0, 0, 1 } };
+            std::vector<uint16_t> ws(WT_SPLIT6_PER_CONV);
+            for (int co = 0; co < 128; co++)
+                for (int ci = 0; ci < 128; ci++) {
+                    const float* g = &w[((size_t)co * 128 + ci) * 9];
+                    for (int pp = 0; pp < 5; pp++)
+                        for (int qq = 0; qq < 5; qq++) {
+                            double u = 0.0;
+                            for (int ky = 0; ky < 3; ky++)
+                                for (int kx = 0; kx < 3; kx++) u += G3[pp][ky] * G3[qq][kx] * (double)g[ky * 3 + kx];
+                            float r = (float)(u * sc[co]);
+                            const int chunk = ci / 32, k = ci % 32;
+                            const size_t stage = (size_t)(chunk * 5 + pp) * 5 + qq;
+                            const size_t lane = (size_t)(k / 8) * 16 + co % 16;
+                            for (int part = 0; part < 3; part++) {
+                                uint32_t bits;
+                                memcpy(&bits, &r, 4);
+                                bits &= 0xffff0000u;
+                                float hf;
+                                memcpy(&hf, &bits, 4);
+                                ws[(((stage * 8 + co / 16) * 3 + part) * 64 + lane) * 8 + k % 8] = (uint16_t)(bits >> 16);
+                                r -= hf;                      // exact
+                            }
+                        }
+                }
+            GOAI_HIP_CHECK(hipMemcpy((uint16_t*)net.wt_split6 + (size_t)l * WT_SPLIT6_PER_CONV, ws.data(),
+                                     ws.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            continue;
+        }
         if (net.wino_mode == 3) {
             // F(3x3,3x3): U = G g Gt (5x5) per (cout, cin) in fp64, BN scale folded
             static const double G3[5][3] = { { 0.5, 0, 0 }, { -0.5, -0.5, -0.5 }, { -1.0 / 6, 1.0 / 6, -1.0 / 6 },
@@ -336,6 +380,10 @@ static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const f
         return launch_conv3x3_bf16(c->S, in, (const uint16_t*)net.wt_bf16 + (size_t)l * WT_BF16_PER_CONV, b, resid, out, M,
                                    c->stream);
     const bool wino = net.wino_mode == 2;
+    if (net.split6)
+        return launch_conv3x3_wino3s(c->S, const_cast<float*>(in), out, resid,
+                                     (const uint16_t*)net.wt_split6 + (size_t)l * WT_SPLIT6_PER_CONV, b, net.wino3p_tab, M / c->P, 1,
+                                     c->stream);
     if (net.wino3_paired)
         return launch_conv3x3_wino3p(c->S, const_cast<float*>(in), out, resid, net.wt_wino3 + (size_t)l * 25 * 128 * 128, b,
                                      net.wino3p_tab, M / c->P, net.n_cu, 1, c->stream);
@@ -388,7 +436,9 @@ static int nn_forward_on(goai_ctx* c, float* const act[3], int cap, bool timed, 
                 c->prof_events.push_back(e1);
                 GOAI_HIP_CHECK(hipEventRecord(e0, c->stream));
             }
-            rc = net.wino3_paired
+            rc = net.split6
+                     ? launch_conv3x3_wino3s(c->S, x, y, nullptr, net.wt_split6, net.bt, net.wino3p_tab, nb, 2 * net.layers, c->stream)
+                 : net.wino3_paired
                      ? launch_conv3x3_wino3p(c->S, x, y, nullptr, net.wt_wino3, net.bt, net.wino3p_tab, nb, net.n_cu,
                                              2 * net.layers, c->stream)
                      : launch_conv3x3_wino3(c->S, x, y, nullptr, net.wt_wino3, net.bt, net.wino3_tab, nb, net.n_cu,
