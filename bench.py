@@ -230,9 +230,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--games", type=int, default=0, help="games per GPU (default: the config's)")
-    ap.add_argument("--dtype", choices=["f32", "bf16x3", "bf16x6"], default="f32",
-                    help="arithmetic of the trunk convolutions: exact fp32 MFMA (default, the reference's precision) "
-                         "or split-operand bf16 MFMA (fp32-grade results, see DESIGN.md)")
+    ap.add_argument("--dtype", choices=["auto", "f32", "bf16x3", "bf16x6"], default="auto",
+                    help="arithmetic of the trunk convolutions.  auto = bf16x6 on 9x9 boards (bf16 matrix cores on operands "
+                         "split exactly into three bf16 parts: fp32-grade results, error at the exact-fp32 Winograd kernel's own "
+                         "level), f32 elsewhere; f32 = exact fp32 MFMA everywhere; bf16x3 = two-part split (1e-5 class, opt-in)")
     ap.add_argument("--groups", type=int, default=1, help="independent game groups on separate HIP streams")
     ap.add_argument("--no-refill", action="store_true",
                     help="leave the slot of a finished game idle instead of starting the next game in it")
@@ -240,6 +241,8 @@ def main():
                     help="gloo: CPU rehearsal of the N-rank launch / rendezvous / gather path with a stub body (no GPU)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    if args.dtype == "auto":
+        args.dtype = "bf16x6" if cfg["size"] == 9 else "f32"
     global SIZE, SIMS, LAYERS
     SIZE, SIMS, LAYERS = cfg["size"], cfg["sims"], cfg["layers"]
 
@@ -361,6 +364,11 @@ def main():
             "ms_per_step": round(t_max / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
+            "precision": {"f32": "fp32 storage and arithmetic (fp32 MFMA)",
+                          "bf16x6": "fp32 storage; trunk products as 6 bf16 MFMAs on operands split exactly into three bf16 parts, "
+                                    "fp32 accumulate and transforms: 6e-6 max rel. error vs the torch fp32 oracle on the 3-block net "
+                                    "(the exact-fp32 F(3x3,3x3) kernel: 7e-6), tolerance 1e-3 (tests/test_gpu_nn.py)",
+                          "bf16x3": "fp32 storage; trunk products as 3 bf16 MFMAs on two-part splits: 2e-5..8e-5 vs torch fp32"}[args.dtype],
             "config": {"workload": f"{cfg['name']}, {n_games} concurrent games per GPU, step = one move of every game "
                                    f"({SIMS + 1} leaf evals per game)",
                        "board": SIZE, "mcts": SIMS, "games_per_gpu": n_games, "parallelism": f"games sharded x{world}",

@@ -52,6 +52,13 @@ struct Wino3S {
     static_assert(IMG_CH_U4 * 16 < 65536, "cell addresses and the chunk offset are 16-bit");
 };
 
+// Diagnostic builds only (tools/wino3s_stamps.sh -DW3S_DIAG=<mask>, tools/wino3s_ablate_run.sh): leave a part of
+// the loop out to see what it costs: 1 weight loads (after the first), 2 output transform (the compiler then drops
+// the MFMAs too), 4 V fragment reads (after the first), 8 input transform and split, 16 the MFMAs.  Results are
+// wrong, timings are the point.
+#ifndef W3S_DIAG
+#define W3S_DIAG 0
+#endif
 #ifdef GOAI_CONV_STAMPS
 // diagnostic build only (tools/wino3p_stamps.py): s_memrealtime (100 MHz) stamps of the SECOND convolution of
 // a launch, 32 per workgroup: 0 layer top, 1 image staged, 2 + 2r transform of row r done (r = 5 cp + p),
@@ -246,8 +253,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
         for (int p = 0; p < 5; p++) {
             const bool stage_next = (p == 4 && cp == 0);       // chunks 2, 3 replace 0, 1 behind the last transform
             if (stage_next) load_img(2);
-            transform(p, 0);
-            transform(p, 1);
+            if (!(W3S_DIAG & 8) || (p == 0 && cp == 0)) {
+                transform(p, 0);
+                transform(p, 1);
+            }
             __syncthreads();                                   // V complete; (p == 4) the image is dead
             W3S_STAMP(2 + 2 * (5 * cp + p));
             if (stage_next) {
@@ -280,19 +289,21 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
                         else if (q < 4) nxt = ((2 * cp) * 5 + p) * 5 + q + 1;
                         else if (p < 4) nxt = ((2 * cp) * 5 + p + 1) * 5;
                         else nxt = (2 * (cp + 1)) * 25;
-                        load_b(nxt < 100 ? nxt : 99, wf[(h + 1) & 1]);     // unconditional: the wait counts stay exact
+                        if (!(W3S_DIAG & 1)) load_b(nxt < 100 ? nxt : 99, wf[(h + 1) & 1]);     // unconditional: the wait counts stay exact
                     }
                     const bf16x8 u0 = __builtin_bit_cast(bf16x8, wf[h & 1][0]), u1 = __builtin_bit_cast(bf16x8, wf[h & 1][1]),
                                  u2 = __builtin_bit_cast(bf16x8, wf[h & 1][2]);
 #pragma unroll
                     for (int t = 0; t < MT; t++) {
                         const int n = h * MT + t;                          // tile step of the row; its fragments sit in vf[n & 1]
-                        if (t + 1 < MT) v_read(q, c, t + 1, vf[(n + 1) & 1]);
+                        if (W3S_DIAG & 4) { vf[(n + 1) & 1][0] = vf[n & 1][0]; vf[(n + 1) & 1][1] = vf[n & 1][1]; vf[(n + 1) & 1][2] = vf[n & 1][2]; }
+                        else if (t + 1 < MT) v_read(q, c, t + 1, vf[(n + 1) & 1]);
                         else if (c == 0) v_read(q, 1, 0, vf[(n + 1) & 1]);
                         else v_read(q < 4 ? q + 1 : 4, 0, 0, vf[(n + 1) & 1]);     // (q == 4: a harmless re-read)
                         const bf16x8 v[3] = { __builtin_bit_cast(bf16x8, vf[n & 1][0]), __builtin_bit_cast(bf16x8, vf[n & 1][1]),
                                               __builtin_bit_cast(bf16x8, vf[n & 1][2]) };
                         // the six products of weight up to 2^-16, smallest first
+                        if (W3S_DIAG & 16) { m[t][0] += __uint_as_float(vf[n & 1][0].x ^ wf[h & 1][0].x); continue; }
                         m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u2, v[0], m[t], 0, 0, 0);
                         m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[2], m[t], 0, 0, 0);
                         m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, v[1], m[t], 0, 0, 0);
@@ -312,7 +323,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
                     const int ci = (i == 0) ? (p < 4 ? 1 : 0)
                                  : (i == 1) ? (p == 1 ? 1 : (p == 2 ? -1 : (p == 3 ? 2 : 0)))
                                             : (p == 0 ? 0 : (p == 3 ? 4 : 1));
-                    if (ci != 0) {
+                    if (ci != 0 && !(W3S_DIAG & 2)) {
                         const float f0 = (float)ci * cj0, f1 = (float)ci * cj1, f2 = (float)ci * cj2;
 #pragma unroll
                         for (int t = 0; t < MT; t++)
