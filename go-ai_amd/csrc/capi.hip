@@ -221,7 +221,7 @@ int goai_mcts_policy_value(goai_ctx* ctx, double temp, int from_values, double* 
     CTX_ENTER(ctx);
     GOAI_REQUIRE(ctx->tree.steps_since_reset >= 0, "call goai_mcts_init and goai_mcts_reset first");
     GOAI_REQUIRE(ctx->tree.mode == GOAI_SEARCH_Q, "needs a context initialised with GOAI_SEARCH_Q");
-    GOAI_REQUIRE(pi != nullptr && temp > 0.0, "pi is NULL or temp <= 0");
+    GOAI_REQUIRE(pi != nullptr, "pi is NULL");
     return launch_q_policy(ctx->S, ctx->tree, temp, from_values, pi, ctx->stream);
 }
 
@@ -274,6 +274,22 @@ int goai_mcts_advance(goai_ctx* ctx, const int32_t* actions)
 {
     CTX_ENTER(ctx);
     return mcts_advance(ctx, actions);
+}
+
+int goai_mcts_node_capacity(goai_ctx* ctx)
+{
+    GOAI_REQUIRE(ctx != nullptr && ctx->tree.n_games > 0, "call goai_mcts_init first");
+    return ctx->tree.ncap;
+}
+
+int goai_mcts_export_tree(goai_ctx* ctx, int game, int32_t* n_nodes, int32_t* parent, int32_t* action, int32_t* visits,
+                          double* value, double* raw_sum, double* prior, uint8_t* states)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(ctx->tree.steps_since_reset >= 0, "call goai_mcts_init and goai_mcts_reset first");
+    GOAI_REQUIRE(game >= 0 && game < ctx->tree.n_games, "no such game");
+    GOAI_REQUIRE(n_nodes && parent && action && visits && value && raw_sum && prior && states, "NULL output");
+    return launch_mcts_export(ctx->S, ctx->tree, game, n_nodes, parent, action, visits, value, raw_sum, prior, states, ctx->stream);
 }
 
 int goai_mcts_set_refill(goai_ctx* ctx, int on)

@@ -26,6 +26,7 @@ struct Tree {
     double* nval = nullptr;      // Q mode: node.val (tree.py:122-126), the critic's value of the node's state
     double* accR = nullptr;      // [..][8] lane accumulators of numpy's pairwise sum over full blocks of 8
     double* accT = nullptr;      // [..][8] pending tail (visits % 8 entries)
+    double* rawsum = nullptr;    // sum of node.post_vals as backed up (raw values, not tanh): only str(node)'s "AV" reads it
     // rows: [G][rcap][A]
     double* prior = nullptr;
     int32_t* child = nullptr;    // node index of the child; -1 = valid move, no node yet; -2 = invalid move
@@ -81,5 +82,7 @@ int launch_sample(int S, const Tree& t, const double* pi, uint64_t seed, uint64_
                   int32_t* actions, hipStream_t st);
 int launch_mcts_advance(int S, const Tree& t, const int32_t* actions, int max_moves, hipStream_t st);
 int launch_mcts_roots(int S, const Tree& t, uint8_t* states, hipStream_t st);
+int launch_mcts_export(int S, const Tree& t, int game, int32_t* n_nodes, int32_t* parent, int32_t* action, int32_t* visits,
+                       double* value, double* raw_sum, double* prior, uint8_t* states, hipStream_t st);
 
 }  // namespace goai

@@ -42,7 +42,7 @@ int mcts_init(goai_ctx* c, int n_games, int max_sims, int mode)
 #define AL(field, count) if ((rc = dev_alloc_t(c, &t.field, (count)))) return rc
     AL(st, N * state_words(c->S));
     AL(parent, N); AL(pact, N); AL(visits, N); AL(rowof, N);
-    AL(accR, N * 8); AL(accT, N * 8);
+    AL(accR, N * 8); AL(accT, N * 8); AL(rawsum, N);
     AL(prior, R * A); AL(child, R * A); AL(crow, R * A); AL(cN, R * A); AL(cQ, R * A);
     AL(nnodes, G); AL(nrows, G); AL(leaf, G); AL(depth, G); AL(path, R);
     AL(turn, G); AL(moves, G); AL(result, G); AL(episode, G); AL(fin, 4 * G);

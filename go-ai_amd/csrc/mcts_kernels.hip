@@ -213,6 +213,7 @@ __device__ __forceinline__ void backprop_path(const Tree& t, int g, double v)
         const size_t xi = nb + X;
         const double tv = (j & 1) ? -T : T;
         const int n = t.visits[xi];
+        t.rawsum[xi] = (n == 0 ? 0.0 : t.rawsum[xi]) + ((j & 1) ? -v : v);   // post_vals as appended (tree.py:142)
         double* R = t.accR + xi * 8;
         double* Tl = t.accT + xi * 8;
         Tl[n & 7] = tv;
@@ -712,6 +713,40 @@ __global__ __launch_bounds__(64) void k_q_policy(Tree t, double temp, int from_v
         }
         if (valid[k]) comp[rank[k]] = fabs(qv[k]);
     }
+    if (temp <= 0.0) {
+        // search.greedy_pi(qs, valid) (/root/reference/go_ai/search/__init__.py:46-52): expq = exp(qs - max(qs)) * valid
+        // over ALL A entries (an invalid move's qs is 0 as a visit count, exp(-0) = 1 as a value), then uniform over the
+        // entries equal to max(expq)
+        double mx = -INFINITY;
+        double full_q[G::K];
+#pragma unroll
+        for (int k = 0; k < G::K; k++) {
+            const int a = lane + 64 * k;
+            full_q[k] = (valid[k] && expanded) ? qv[k] : ((from_values && expanded) ? 1.0 : 0.0);
+            if (a < G::A) mx = fmax(mx, full_q[k]);
+        }
+        mx = wave_max_f64(mx);
+        double ex[G::K], emax = 0.0;
+#pragma unroll
+        for (int k = 0; k < G::K; k++) {
+            ex[k] = valid[k] ? det_exp64(full_q[k] - mx) : 0.0;
+            emax = fmax(emax, ex[k]);
+        }
+        emax = wave_max_f64(emax);
+        int hits = 0;
+        bool hit[G::K];
+#pragma unroll
+        for (int k = 0; k < G::K; k++) {
+            hit[k] = (lane + 64 * k) < G::A && ex[k] == emax;
+            hits += __popcll(__ballot(hit[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < G::K; k++) {
+            const int a = lane + 64 * k;
+            if (a < G::A) pi[(size_t)g * G::A + a] = hit[k] ? 1.0 / (double)hits : 0.0;
+        }
+        return;
+    }
     __syncthreads();
     if (lane == 0) total = np_pairwise_sum(comp, nvalid);
     __syncthreads();
@@ -737,6 +772,43 @@ __global__ __launch_bounds__(64) void k_q_policy(Tree t, double temp, int from_v
             pi[(size_t)g * G::A + a] = (expanded && s2 > 0.0) ? full[a] / s2 : noise;
         }
     }
+}
+
+// The whole tree of one game, node by node, for the host-side Node views (tree.Node's fields,
+// /root/reference/go_ai/search/tree.py:22-52): parent, the action that led to the node, visits, node.val
+// (Q mode; NaN where none), the sum of node.post_vals, the prior row (NaN row where the node has none) and
+// node.state.  One wavefront per node slot; slots beyond the game's node count are left alone.
+template <int S>
+__global__ __launch_bounds__(64) void k_mcts_export(Tree t, int g, int32_t* __restrict__ n_nodes,
+                                                    int32_t* __restrict__ parent, int32_t* __restrict__ action,
+                                                    int32_t* __restrict__ visits, double* __restrict__ value,
+                                                    double* __restrict__ raw_sum, double* __restrict__ prior,
+                                                    uint8_t* __restrict__ states)
+{
+    using G = Geom<S>;
+    const int n = blockIdx.x, lane = lane_id();
+    const size_t nb = (size_t)g * t.ncap;
+    const int count = t.nnodes[g];
+    if (n == 0 && lane == 0) *n_nodes = count;
+    if (n >= count) return;
+    const size_t xi = nb + n;
+    const int vis = t.visits[xi];
+    const int row = t.rowof[xi];
+    uint64_t me[G::K], opp[G::K], inv[G::K], meta;
+    node_load<S>(t, xi, me, opp, inv, meta);
+    // a row holds a prior once the node was evaluated as a non-terminal leaf (visited at least once)
+    const bool has_prior = row >= 0 && vis > 0 && !(meta & FLAG_DONE);
+    if (lane == 0) {
+        parent[n] = t.parent[xi];
+        action[n] = t.pact[xi];
+        visits[n] = vis;
+        value[n] = (t.nval && n > 0) ? t.nval[xi] : __longlong_as_double(0x7ff8000000000000ll);
+        raw_sum[n] = vis > 0 ? t.rawsum[xi] : 0.0;
+    }
+    for (int a = lane; a < G::A; a += 64)
+        prior[(size_t)n * G::A + a] = has_prior ? t.prior[((size_t)g * t.rcap + row) * G::A + a]
+                                                : __longlong_as_double(0x7ff8000000000000ll);
+    planes_store<S>(states + (size_t)n * 6 * G::P, me, opp, inv, 0, (uint32_t)(meta & 7u));
 }
 
 // ---- launchers -----------------------------------------------------------------------------
@@ -774,6 +846,15 @@ int launch_mcts_advance(int S_rt, const Tree& t, const int32_t* actions, int max
     LAUNCH_PER_GAME(k_mcts_advance, t, actions, max_moves);
 }
 int launch_mcts_roots(int S_rt, const Tree& t, uint8_t* states, hipStream_t st) { LAUNCH_PER_GAME(k_mcts_roots, t, states); }
+
+int launch_mcts_export(int S_rt, const Tree& t, int game, int32_t* n_nodes, int32_t* parent, int32_t* action, int32_t* visits,
+                       double* value, double* raw_sum, double* prior, uint8_t* states, hipStream_t st)
+{
+    GOAI_DISPATCH_SIZE(S_rt, k_mcts_export<S><<<dim3(t.ncap), dim3(64), 0, st>>>(t, game, n_nodes, parent, action, visits, value,
+                                                                               raw_sum, prior, states));
+    GOAI_HIP_CHECK(hipGetLastError());
+    return GOAI_OK;
+}
 
 int launch_q_scan(const Tree& t, hipStream_t st)
 {

@@ -39,6 +39,7 @@ class Context:
         self._h = h
         self.net_kind = -1
         self.n_games = self.max_sims = self.search_mode = 0
+        self.search_generation = 0           # bumped by every mcts_reset: tree views check it before reading the tree
         self.set_stream(torch.cuda.current_stream(self.device))
 
     def close(self):
@@ -186,6 +187,7 @@ class Context:
         self._bind()
         st = _dev_u8_states(root_states, self.device)
         assert self.n_games == 0 or st.shape == (self.n_games, NUM_CHNLS, self.size, self.size), st.shape
+        self.search_generation += 1
         _hip.check(_hip.lib.goai_mcts_reset(self._h, _hip.ptr(st)))
 
     def mcts_select(self, want_leaves=True):
@@ -278,6 +280,27 @@ class Context:
         self._bind()
         acts = torch.as_tensor(actions).to(self.device, dtype=torch.int32).contiguous()
         _hip.check(_hip.lib.goai_mcts_advance(self._h, _hip.ptr(acts)))
+
+    def mcts_export_tree(self, game=0):
+        """The whole tree of one game as host arrays: dict(parent, action, visits, value, raw_sum, prior, states),
+        one entry per node, node 0 = the root (goai_mcts_export_tree)."""
+        self._bind()
+        cap = _hip.lib.goai_mcts_node_capacity(self._h)
+        if cap < 0:
+            _hip.check(cap)
+        dev = self.device
+        n = torch.zeros(1, dtype=torch.int32, device=dev)
+        parent, action, visits = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(3)]
+        value, raw_sum = [torch.empty(cap, dtype=torch.float64, device=dev) for _ in range(2)]
+        prior = torch.empty((cap, self.A), dtype=torch.float64, device=dev)
+        states = torch.empty((cap, NUM_CHNLS, self.size, self.size), dtype=torch.uint8, device=dev)
+        _hip.check(_hip.lib.goai_mcts_export_tree(self._h, int(game), _hip.ptr(n), _hip.ptr(parent), _hip.ptr(action),
+                                                  _hip.ptr(visits), _hip.ptr(value), _hip.ptr(raw_sum), _hip.ptr(prior),
+                                                  _hip.ptr(states)))
+        k = int(n.item())
+        return dict(parent=parent[:k].cpu().numpy(), action=action[:k].cpu().numpy(), visits=visits[:k].cpu().numpy(),
+                    value=value[:k].cpu().numpy(), raw_sum=raw_sum[:k].cpu().numpy(), prior=prior[:k].cpu().numpy(),
+                    states=states[:k].cpu().numpy())
 
     def mcts_set_refill(self, on=True):
         """Finished games are replaced by fresh ones (empty board) in their slot by mcts_advance."""

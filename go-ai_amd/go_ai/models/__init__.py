@@ -62,6 +62,7 @@ class RLNet:
     """Counterpart of the reference's RLNet (/root/reference/go_ai/models/__init__.py:13-113),
     inference half: weights live on the GPU inside a go_ai.engine.Context."""
     kind = None
+    MAX_SEARCH_CONTEXTS = 4      # tree storage is kept for the last few (n_games, max_sims, mode) combinations only
 
     def __init__(self, size, device=0, n_blocks=LAYERS, max_batch=512):
         from ..engine import Context
@@ -99,7 +100,11 @@ class RLNet:
         """A context with tree storage for (n_games, max_sims, search mode), sharing this net's weights."""
         from ..engine import Context
         key = (n_games, max_sims, mode)
-        if key not in self._search:
+        if key in self._search:
+            self._search[key] = self._search.pop(key)            # most recently used last
+        else:
+            while len(self._search) >= self.MAX_SEARCH_CONTEXTS:  # drop the least recently used one (frees its trees)
+                self._search.pop(next(iter(self._search))).close()
             c = Context(self.size, self.device_index)
             batch = n_games if mode == Context.SEARCH_AC else min(n_games * (self.size ** 2 + 2), 16384)
             c.nn_init(Context.NET_AC if self.kind == "ac" else Context.NET_VAL, self.layers, max(batch, 1))
@@ -112,6 +117,8 @@ class RLNet:
     def create_numpy(self, mode):
         def np_func(states):
             return self._numpy(states, mode)
+        np_func._goai_net = self          # mct_search keeps the whole search on the GPU for callables that carry this
+        np_func._goai_mode = mode
         return np_func
 
     def _numpy(self, states, mode, children=None):

@@ -20,11 +20,16 @@ from ..engine import Context
 from .tree import RootView
 
 _plain_ctx = {}
+_MAX_PLAIN_CTX = 4       # tree-only contexts for foreign callables: the last few (size, searches, mode) are kept
 
 
 def _tree_context(size, num_searches, mode=Context.SEARCH_AC):
     key = (size, num_searches, mode)
-    if key not in _plain_ctx:
+    if key in _plain_ctx:
+        _plain_ctx[key] = _plain_ctx.pop(key)                    # most recently used last
+    else:
+        while len(_plain_ctx) >= _MAX_PLAIN_CTX:
+            _plain_ctx.pop(next(iter(_plain_ctx))).close()
         c = Context(size)
         c.mcts_init(1, num_searches, mode)
         _plain_ctx[key] = c
@@ -56,21 +61,23 @@ def _critic_search(root_state, num_searches, critic):
     valid_root = np.append(root_state[3].flatten() == 0, True)
     child_vals = np.where(valid_root, -inv, np.nan)
     root = RootView(root_state, visits[0].cpu().numpy(), prior[0].cpu().numpy(), root_visits[0].item(), child_vals)
-    root._ctx = ctx
+    root.attach(ctx)
     return root
 
 
 def _owning_net(fn):
-    """The go_ai.models net behind a create_numpy closure, if any."""
-    cells = getattr(fn, "__closure__", None) or ()
+    """The go_ai.models net behind a create_numpy callable: RLNet.create_numpy marks what it returns
+    with `_goai_net` (functools.partial objects and bound methods of such a callable are looked through).
+    None for any other callable: it is then evaluated on the host, one call per search step."""
     from ..models import RLNet
-    for cell in cells:
-        try:
-            v = cell.cell_contents
-        except ValueError:
-            continue
-        if isinstance(v, RLNet):
-            return v
+    for _ in range(4):
+        net = getattr(fn, "_goai_net", None)
+        if isinstance(net, RLNet):
+            return net
+        inner = getattr(fn, "func", None) or getattr(fn, "__wrapped__", None) or getattr(fn, "__func__", None)
+        if inner is None:
+            return None
+        fn = inner
     return None
 
 
@@ -95,5 +102,5 @@ def mct_search(go_env, num_searches, actor_critic=None, critic=None):
                             pi_logits=np.asarray(pi_logits, dtype=np.float32).reshape(1, -1), logits_are_raw=False)
     visits, prior, root_visits = ctx.mcts_readout()
     root = RootView(root_state, visits[0].cpu().numpy(), prior[0].cpu().numpy(), root_visits[0].item())
-    root._ctx = ctx
+    root.attach(ctx)
     return root

@@ -217,10 +217,12 @@ int goai_mcts_backup_q(goai_ctx* ctx, const double* leaf_val, const double* chil
  * 0 where the root has no child.  GOAI_SEARCH_Q only. */
 int goai_mcts_child_values(goai_ctx* ctx, double* inverted_child_vals);
 
-/* Value.__call__ for temp > 0 (/root/reference/go_ai/policies/value.py:30-37):
+/* Value.__call__ (/root/reference/go_ai/policies/value.py:30-37):
  * pi [n_games][A] float64 = search.temp_norm(qs, temp, valid) (search/__init__.py:78-87) with
  * qs = root visit counts (from_values == 0, mcts > 0) or exp(-child values) (from_values != 0,
- * mcts == 0).  Bit-exact for temp == 1.  GOAI_SEARCH_Q only. */
+ * mcts == 0).  temp <= 0: search.greedy_pi (search/__init__.py:46-52), uniform over the best moves.
+ * Bit-exact for temp == 1 and temp <= 0; other temperatures go through pow() (within 4 ulp of numpy's).
+ * GOAI_SEARCH_Q only. */
 int goai_mcts_policy_value(goai_ctx* ctx, double temp, int from_values, double* pi);
 
 /* mct_search with the context's own network: 1 + n_sims times select -> forward -> backup
@@ -257,6 +259,16 @@ int goai_sample_actions(goai_ctx* ctx, const double* pi, uint64_t seed, uint64_t
 /* go_env.step(action) for every running game followed by a fresh tree (game.py:95,
  * mct.py:52-53).  A game ends after two passes or more than 2*S*S moves (game.py:74,98). */
 int goai_mcts_advance(goai_ctx* ctx, const int32_t* actions);
+
+/* The whole search tree of one game, for host-side views of tree.Node (/root/reference/go_ai/search/tree.py:22-52;
+ * what policy(go_env, debug=True) hands to search/plot.py:39-61).  Node n < *n_nodes (all device arrays sized
+ * goai_mcts_node_capacity()): parent[n] (-1 for the root, node 0), action[n] = the move that led to it,
+ * visits[n], value[n] = node.val (GOAI_SEARCH_Q; NaN where none), raw_sum[n] = sum(node.post_vals),
+ * prior [n][A] = node.prior_pi (a NaN row where the node has none), states [n][6][S][S] = node.state.
+ * Children follow their parent; an actor-critic tree lists nodes in creation order. */
+int goai_mcts_node_capacity(goai_ctx* ctx);
+int goai_mcts_export_tree(goai_ctx* ctx, int game, int32_t* n_nodes, int32_t* parent, int32_t* action, int32_t* visits,
+                          double* value, double* raw_sum, double* prior, uint8_t* states);
 
 /* Slot refill for long self-play runs (play_games' loop over episodes, /root/reference/go_ai/game.py:139-145,
  * with every slot of the batch as one sequential player): when on, goai_mcts_advance replaces a game that just

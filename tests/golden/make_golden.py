@@ -299,8 +299,60 @@ def gen_policy_kat():
                         canonical=env.canonical_state().astype(np.uint8), pi=pi)
 
 
+def gen_search_helpers():
+    """Direct input / output vectors of the reference's policy helpers
+    (/root/reference/go_ai/search/__init__.py:9-97): invert_vals, greedy_pi, batch_greedy_pi, temp_softmax,
+    temp_norm, batch_temperate_pi at temperatures 0, 0.5, 1 and 2, on random q values with ties, random
+    valid masks (the pass always valid) and visit-count-like integer inputs."""
+    from go_ai import search as ref_search
+    rng = np.random.default_rng(77)
+    n, A = 24, 26
+    valid = (rng.random((n, A)) < 0.7).astype(np.float64)
+    valid[:, -1] = 1
+    q = rng.standard_normal((n, A)) * 2
+    q[0:4] = np.round(q[0:4])                       # ties
+    q[4] = 0.0                                      # all equal
+    counts = rng.integers(0, 12, (n, A)).astype(np.float64) * valid
+    counts[:, -1] += 1                              # never all zero
+    temps = np.array([0.0, 0.5, 1.0, 2.0])
+    out = dict(q=q, valid=valid, counts=counts, temps=temps, invert=ref_search.invert_vals(q))
+    out["greedy_pi"] = np.stack([ref_search.greedy_pi(q[i], valid[i]) for i in range(n)])
+    out["greedy_pi_counts"] = np.stack([ref_search.greedy_pi(counts[i], valid[i]) for i in range(n)])
+    out["batch_greedy_pi"] = ref_search.batch_greedy_pi(q.copy(), valid)
+    for ti, t in enumerate(temps):
+        out[f"temp_softmax_{ti}"] = np.stack([ref_search.temp_softmax(q[i], t, valid[i]) for i in range(n)])
+        out[f"temp_norm_exp_{ti}"] = np.stack([ref_search.temp_norm(np.exp(q[i]), t, valid[i]) for i in range(n)])
+        out[f"temp_norm_counts_{ti}"] = np.stack([ref_search.temp_norm(counts[i], t, valid[i]) for i in range(n)])
+        out[f"batch_temperate_pi_{ti}"] = ref_search.batch_temperate_pi(q.copy(), t, valid)
+    path = os.path.join(HERE, "search_helpers.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path)
+
+
+def gen_temps():
+    """The reference's policies at temperatures other than 1 (actorcritic.py:33-40, value.py:31-37,
+    search/__init__.py:78-87): counts ** (1 / T) for the actor-critic policy; temp_norm -- and, for T <= 0,
+    greedy_pi -- for the Value policy, with and without search."""
+    net5, _ = ref_net("ac", 5, 11)
+    val5, _ = ref_net("val", 5, 21)
+    roots5 = [s.astype(np.float64) for s in random_positions(5, 6, 7, max_moves=18, canonical=False)]
+    roots5[0] = og.GoGame.get_init_board(5)
+    roots5[1] = og.GoGame.next_state(roots5[1], 25, canonical=False)
+    for tag, temp in (("t05", 0.5), ("t2", 2.0)):
+        gen_mcts_ac(f"ac5_n8_{tag}", 5, 8, roots5, lambda i: net5.create_numpy("actor_critic"), temp=temp)
+        gen_mcts_q(f"val5_n12_{tag}", 5, 12, roots5, lambda i: val5.create_numpy("critic"), temp=temp)
+        gen_mcts_q(f"val5_n0_{tag}", 5, 0, roots5, lambda i: val5.create_numpy("critic"), temp=temp)
+    gen_mcts_q("val5_n12_t0", 5, 12, roots5, lambda i: val5.create_numpy("critic"), temp=0.0)
+    gen_mcts_q("val5_n0_t0", 5, 0, roots5, lambda i: val5.create_numpy("critic"), temp=0.0)
+    gen_mcts_q("fake_flat5_n30_t0", 5, 30, roots5[:3], lambda i: fake_critic("flat", np.random.default_rng(300 + i)), temp=0.0)
+
+
 def main():
     torch.manual_seed(0)
+    if "--only-temps" in sys.argv:       # add the temperature / helper fixtures without rewriting the others
+        gen_search_helpers()
+        gen_temps()
+        return
     only_q = "--only-q" in sys.argv      # add the Q-search fixtures without rewriting the others
     if only_q:
         global gen_policy_kat, gen_nn, gen_mcts_ac
@@ -345,6 +397,8 @@ def main():
         gen_mcts_q(f"fake_{style}5_n30", 5, 30, roots5[:3],
                    lambda i, style=style: fake_critic(style, np.random.default_rng(300 + i)))
     gen_mcts_q("fake_wide9_n20", 9, 20, roots9[:2], lambda i: fake_critic("wide", np.random.default_rng(400 + i)))
+    gen_search_helpers()
+    gen_temps()
 
 
 if __name__ == "__main__":

@@ -54,9 +54,16 @@ def test_replay_reference_q_search(name):
         assert root_visits[i] == cs["root_visits"]
         assert np.array_equal(inv_vals[i], cs["inv_child_vals"])
         assert np.allclose(prior[i], cs["root_prior"], rtol=1e-12, atol=1e-300)
-        if sims > 0:
+        if temp <= 0:
+            assert np.array_equal(pi[i], cs["pi"])        # search.greedy_pi: uniform over the best moves, exact
+        elif sims > 0 and temp == 1.0:
             assert np.array_equal(pi[i], cs["pi"])        # integer counts: exact
+        elif temp == 1.0:
+            assert np.allclose(pi[i], cs["pi"], rtol=1e-12, atol=0)     # exp(-child values): the deterministic exp
         else:
+            # temp_norm's ** (1 / T) (search/__init__.py:85): the device pow(), and for mcts = 0 the deterministic
+            # exp under it; bound 1e-12 relative on every entry
+            assert np.array_equal(pi[i] == 0, cs["pi"] == 0)
             assert np.allclose(pi[i], cs["pi"], rtol=1e-12, atol=0)
 
 

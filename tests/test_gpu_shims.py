@@ -41,6 +41,91 @@ def test_mct_search_with_foreign_callable_matches_golden():
         assert root.visits == c["root_visits"]
 
 
+def test_tree_views_match_the_reference_node_surface():
+    """rootnode.child_nodes / winning() / str(node) (tree.py:65-69,100-108,186-195), what search/plot.py:39-61 and the
+    policies' debug return walk: the whole GPU tree exported once and compared node by node with the sequential oracle's
+    tree built from the same recorded network outputs (actor-critic and Q-value searches)."""
+    from golden_util import ReplayCritic
+    from go_ai.env import GoEnv
+    from go_ai.search import mct
+    from oracle import mcts_ref
+    from oracle.gogame import GoEnv as OEnv, GoGame as OG
+
+    def same(view, ref, depth=0):
+        assert view.visits == ref.visits and view.level == ref.level == depth
+        assert np.array_equal(view.state, ref.state)
+        assert view.terminal() == ref.terminal() and view.isroot() == (ref.parent is None)
+        if ref.prior_pi is None:
+            assert view.prior_pi is None
+        else:
+            assert np.allclose(view.prior_pi, ref.prior_pi, rtol=2e-6, atol=1e-30)   # fp32 det-softmax vs scipy's
+        assert (view.val is None) == (ref.val is None) and (ref.val is None or view.val == ref.val)
+        assert np.array_equal(view.get_visit_counts(), [0 if c is None else c.visits for c in ref.child_nodes])
+        assert len(view.get_child_nodes()) == len([c for c in ref.child_nodes if c is not None])
+        want = (f'{ref.val:.2f}V' if ref.val is not None else '') + \
+               (f' {np.mean(ref.post_vals):.2f}AV' if len(ref.post_vals) > 0 else '') + f' {ref.level}L {ref.visits}N'
+        assert str(view) == want, (str(view), want)                                   # tree.py:186-195
+        n = 1
+        for a, (cv, cr) in enumerate(zip(view.child_nodes, ref.child_nodes)):
+            assert (cv is None) == (cr is None), (depth, a)
+            if cv is not None:
+                assert cv.parent is view and cv.first_action == (a if depth == 0 else view.first_action)
+                n += same(cv, cr, depth + 1)
+        return n
+
+    size, sims, temp, cases = load_mcts("mcts_ac5_n40")
+    for c in cases[:2]:
+        env = GoEnv(size)
+        env.state = c["root"].astype(np.float64)
+        root = mct.mct_search(env, sims, actor_critic=ReplayNet(c))
+        oenv = OEnv(size)
+        oenv.state = c["root"].astype(np.float64)
+        _, _, oroot = mcts_ref.actor_critic_policy(oenv, ReplayNet(c), sims, temp, math="numpy")
+        def count(n):
+            return 1 + sum(count(k) for k in n.child_nodes if k is not None)
+        assert same(root, oroot) == count(oroot) <= sims + 1      # at most one new node per search step
+        assert root.winning() == OG.winning(c["root"].astype(np.float64))
+        assert not root.isleaf() and root.actionsize() == size * size + 1
+    size, sims, temp, cases = load_mcts("mctsq_val5_n12")
+    c = cases[0]
+    env = GoEnv(size)
+    env.state = c["root"].astype(np.float64)
+    root = mct.mct_search(env, sims, critic=ReplayCritic(c))
+    oenv = OEnv(size)
+    oenv.state = c["root"].astype(np.float64)
+    _, oroot = mcts_ref.value_policy(oenv, ReplayCritic(c), sims, temp, math="numpy")
+    assert same(root, oroot) > sims + 1               # every expansion made all valid children
+    assert np.array_equal(root.inverted_children_values(), c["inv_child_vals"])
+    # a later search on the same context overwrites the tree: a view that was not loaded says so
+    stale = mct.mct_search(env, sims, critic=ReplayCritic(c))
+    mct.mct_search(env, sims, critic=ReplayCritic(c))
+    with pytest.raises(RuntimeError, match="overwritten"):
+        stale.child_nodes
+
+
+def test_mct_search_keeps_wrapped_gpu_nets_on_the_gpu():
+    """mct_search recognises a go_ai.models net behind create_numpy's callable by the attribute the callable
+    carries, also through functools.partial (no closure poking): the search then runs in the net's own context."""
+    import functools
+    from go_ai.env import GoEnv
+    from go_ai.models.ac_net import ActorCriticNet
+    from go_ai.search import mct
+    net = ActorCriticNet(5, max_batch=32)
+    f = net.create_numpy('actor_critic')
+    assert mct._owning_net(f) is net and mct._owning_net(functools.partial(f)) is net
+    assert mct._owning_net(lambda s: f(s)) is None
+    env = GoEnv(5)
+    env.reset()
+    a = mct.mct_search(env, 10, actor_critic=f).get_visit_counts()
+    b = mct.mct_search(env, 10, actor_critic=functools.partial(f)).get_visit_counts()
+    c = mct.mct_search(env, 10, actor_critic=lambda s: f(s)).get_visit_counts()      # host callback path, same numbers
+    assert np.array_equal(a, b) and np.array_equal(a, c) and a.sum() == 10
+    # the net keeps tree storage for a few (games, searches, mode) combinations only
+    for sims in range(1, 8):
+        mct.mct_search(env, sims, actor_critic=f)
+    assert len(net._search) <= net.MAX_SEARCH_CONTEXTS
+
+
 def test_actorcritic_policy_on_gpu_net():
     from go_ai.env import GoEnv
     from go_ai.models.ac_net import ActorCriticNet
