@@ -276,6 +276,25 @@ int goai_mcts_advance(goai_ctx* ctx, const int32_t* actions)
     return mcts_advance(ctx, actions);
 }
 
+int goai_mcts_set_active(goai_ctx* ctx, int n_active)
+{
+    GOAI_REQUIRE(ctx != nullptr && ctx->tree.n_games > 0, "call goai_mcts_init first");
+    GOAI_REQUIRE(n_active >= 1 && n_active <= ctx->tree.n_games, "n_active must be in [1, n_games]");
+    ctx->tree.n_active = n_active;
+    ctx->tree.steps_since_reset = -1;         // the roots must be set again
+    return GOAI_OK;
+}
+
+int goai_sample_actions_keyed(goai_ctx* ctx, const double* pi, uint64_t seed, const uint64_t* game_ids,
+                              const int32_t* steps, int n, int32_t* actions)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return GOAI_OK;
+    GOAI_REQUIRE(pi && game_ids && steps && actions, "NULL array argument");
+    return launch_sample_keyed(ctx->S, pi, seed, game_ids, steps, n, actions, ctx->stream);
+}
+
 int goai_mcts_node_capacity(goai_ctx* ctx)
 {
     GOAI_REQUIRE(ctx != nullptr && ctx->tree.n_games > 0, "call goai_mcts_init first");
@@ -321,7 +340,7 @@ int goai_mcts_roots(goai_ctx* ctx, uint8_t* states, int32_t* turn, int32_t* move
     CTX_ENTER(ctx);
     const goai::Tree& t = ctx->tree;
     GOAI_REQUIRE(t.steps_since_reset >= 0, "call goai_mcts_init and goai_mcts_reset first");
-    const size_t bytes = (size_t)t.n_games * sizeof(int32_t);
+    const size_t bytes = (size_t)t.n_active * sizeof(int32_t);
     if (turn) GOAI_HIP_CHECK(hipMemcpyAsync(turn, t.turn, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     if (moves) GOAI_HIP_CHECK(hipMemcpyAsync(moves, t.moves, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     if (result) GOAI_HIP_CHECK(hipMemcpyAsync(result, t.result, bytes, hipMemcpyDeviceToDevice, ctx->stream));

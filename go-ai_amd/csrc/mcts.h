@@ -12,6 +12,7 @@ namespace goai {
 
 struct Tree {
     int n_games = 0, max_sims = 0, mode = 0;
+    int n_active = 0;            // games the calls work on: the first n_active slots (goai_mcts_set_active; default all)
     int ncap = 0;                // nodes per game: AC max_sims + 2 (one new node per step); Q 2 + (max_sims + 1) * A
     int rcap = 0;                // expanded nodes (rows) and path entries per game: max_sims + 2 in both modes
     int steps_since_reset = 0;
@@ -80,6 +81,8 @@ int launch_q_policy(int S, const Tree& t, double temp, int from_values, double* 
 int launch_uniform_policy(int S, const Tree& t, int allow_pass, double* pi, hipStream_t st);
 int launch_sample(int S, const Tree& t, const double* pi, uint64_t seed, uint64_t step, int game_offset,
                   int32_t* actions, hipStream_t st);
+int launch_sample_keyed(int S, const double* pi, uint64_t seed, const uint64_t* game_ids, const int32_t* steps, int n,
+                        int32_t* actions, hipStream_t st);
 int launch_mcts_advance(int S, const Tree& t, const int32_t* actions, int max_moves, hipStream_t st);
 int launch_mcts_roots(int S, const Tree& t, uint8_t* states, hipStream_t st);
 int launch_mcts_export(int S, const Tree& t, int game, int32_t* n_nodes, int32_t* parent, int32_t* action, int32_t* visits,

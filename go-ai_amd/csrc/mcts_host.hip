@@ -66,6 +66,7 @@ int mcts_init(goai_ctx* c, int n_games, int max_sims, int mode)
     GOAI_HIP_CHECK(hipMemset(t.episode, 0, G * sizeof(int32_t)));
     GOAI_HIP_CHECK(hipMemset(t.fin, 0, 4 * G * sizeof(long long)));
     t.n_games = n_games;
+    t.n_active = n_games;
     t.steps_since_reset = -1;   // no roots yet
     return GOAI_OK;
 }
@@ -162,11 +163,11 @@ int mcts_steps(goai_ctx* c, int n_steps)
             if ((rc = mcts_select(c, nullptr))) return rc;
             if ((rc = mcts_expand(c, nullptr, nullptr))) return rc;
             // the batch size is data dependent (number of legal moves of every leaf)
-            GOAI_HIP_CHECK(hipMemcpyAsync(t.q_total_host, t.q_off + t.n_games, sizeof(int32_t), hipMemcpyDeviceToHost,
+            GOAI_HIP_CHECK(hipMemcpyAsync(t.q_total_host, t.q_off + t.n_active, sizeof(int32_t), hipMemcpyDeviceToHost,
                                           c->stream));
             GOAI_HIP_CHECK(hipStreamSynchronize(c->stream));
             const int total = *t.q_total_host;
-            GOAI_REQUIRE(total >= t.n_games && (size_t)total <= (size_t)t.n_games * (1 + c->A), "corrupt batch size");
+            GOAI_REQUIRE(total >= t.n_active && (size_t)total <= (size_t)t.n_active * (1 + c->A), "corrupt batch size");
             if ((rc = nn_forward_raw(c, t.q_planes, nullptr, t.q_vals, total))) return rc;
             if ((rc = mcts_backup_q(c, nullptr, nullptr, 1))) return rc;
         }
@@ -175,7 +176,7 @@ int mcts_steps(goai_ctx* c, int n_steps)
     GOAI_REQUIRE(c->net.loaded && c->net.kind == 0, "an actor-critic network with loaded weights is required");
     for (int s = 0; s < n_steps; s++) {
         if ((rc = mcts_select(c, nullptr))) return rc;
-        if ((rc = nn_forward_raw(c, t.leaf_planes, t.pi_logits, t.val_logits, t.n_games))) return rc;
+        if ((rc = nn_forward_raw(c, t.leaf_planes, t.pi_logits, t.val_logits, t.n_active))) return rc;
         if ((rc = mcts_backup(c, t.pi_logits, nullptr, t.val_logits, 1))) return rc;
     }
     return GOAI_OK;

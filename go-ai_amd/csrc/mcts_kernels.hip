@@ -386,6 +386,27 @@ __global__ __launch_bounds__(64) void k_mcts_policy(Tree t, double temp, int uni
 // GoGame.random_weighted_action(pi) (/root/reference/go_ai/game.py:91): inverse-CDF draw with
 // a Philox stream per (seed, game, step).  The reference draws from numpy's unseeded global
 // generator, so parity is on pi, not on the drawn action.
+__device__ __forceinline__ int sample_action(const double* p, int A, int P, uint64_t gid, uint64_t step, uint64_t seed)
+{
+    uint32_t r[4];
+    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    const double u = (double)((((uint64_t)r[0] << 32) | r[1]) >> 11) * 0x1p-53;
+    double total = 0.0;
+    for (int a = 0; a < A; a++) total += p[a];
+    const double target = u * total;
+    double cum = 0.0;
+    int pick = -1, last = P;
+    for (int a = 0; a < A; a++) {
+        if (p[a] > 0.0) {
+            last = a;
+            cum += p[a];
+            if (pick < 0 && cum > target) pick = a;
+        }
+    }
+    return pick >= 0 ? pick : last;
+}
+
 template <int S>
 __global__ __launch_bounds__(64) void k_sample(Tree t, const double* __restrict__ pi, uint64_t seed, uint64_t step,
                                                int game_offset, int32_t* __restrict__ actions)
@@ -393,26 +414,23 @@ __global__ __launch_bounds__(64) void k_sample(Tree t, const double* __restrict_
     using G = Geom<S>;
     const int g = blockIdx.x;
     if (lane_id() != 0) return;
-    const double* p = pi + (size_t)g * G::A;
-    uint32_t r[4];
     // global game id: the slot's id, plus (refill mode) how many games the slot has already finished
     const uint64_t gid = (uint64_t)(g + game_offset) + ((uint64_t)(uint32_t)t.episode[g] << 32);
-    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
-                  (uint32_t)(seed >> 32), r);
-    const double u = (double)((((uint64_t)r[0] << 32) | r[1]) >> 11) * 0x1p-53;
-    double total = 0.0;
-    for (int a = 0; a < G::A; a++) total += p[a];
-    const double target = u * total;
-    double cum = 0.0;
-    int pick = -1, last = G::P;
-    for (int a = 0; a < G::A; a++) {
-        if (p[a] > 0.0) {
-            last = a;
-            cum += p[a];
-            if (pick < 0 && cum > target) pick = a;
-        }
-    }
-    actions[g] = pick >= 0 ? pick : last;
+    actions[g] = sample_action(pi + (size_t)g * G::A, G::A, G::P, gid, step, seed);
+}
+
+// The same draw with the Philox key given per row: game_ids[i] and steps[i] (the game's own move number), for
+// callers that keep the games themselves and hand a context a different subset every move (go_ai.game.BatchedPlay).
+template <int S>
+__global__ __launch_bounds__(64) void k_sample_keyed(const double* __restrict__ pi, uint64_t seed,
+                                                     const uint64_t* __restrict__ game_ids,
+                                                     const int32_t* __restrict__ steps, int n,
+                                                     int32_t* __restrict__ actions)
+{
+    using G = Geom<S>;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    actions[i] = sample_action(pi + (size_t)i * G::A, G::A, G::P, game_ids[i], (uint64_t)(uint32_t)steps[i], seed);
 }
 
 // go_env.step(action) for every running game, then a fresh tree (the reference builds a
@@ -491,7 +509,7 @@ __global__ __launch_bounds__(64) void k_mcts_roots(Tree t, uint8_t* __restrict__
 __global__ __launch_bounds__(1024) void k_q_scan(Tree t)
 {
     __shared__ int part[1024];
-    const int tid = threadIdx.x, G = t.n_games;
+    const int tid = threadIdx.x, G = t.n_active;
     const int per = (G + 1023) / 1024;
     const int lo = tid * per, hi = min(G, lo + per);
     int sum = 0;
@@ -539,7 +557,7 @@ __global__ __launch_bounds__(64) void k_q_expand(Tree t, uint8_t* __restrict__ c
     using G = Geom<S>;
     __shared__ BoardLds<S> L;
     board_init_border<S>(L);
-    const long total = (long)t.n_games * G::A;
+    const long total = (long)t.n_active * G::A;
     for (long w = blockIdx.x; w < total; w += gridDim.x) {
         const int g = (int)(w / G::A), a = (int)(w % G::A), lane = lane_id();
         const size_t nb = (size_t)g * t.ncap, rb = (size_t)g * t.rcap;
@@ -813,7 +831,7 @@ __global__ __launch_bounds__(64) void k_mcts_export(Tree t, int g, int32_t* __re
 
 // ---- launchers -----------------------------------------------------------------------------
 #define LAUNCH_PER_GAME(KERNEL, ...)                                                              \
-    GOAI_DISPATCH_SIZE(S_rt, KERNEL<S><<<dim3(t.n_games), dim3(64), 0, st>>>(__VA_ARGS__));       \
+    GOAI_DISPATCH_SIZE(S_rt, KERNEL<S><<<dim3(t.n_active), dim3(64), 0, st>>>(__VA_ARGS__));      \
     GOAI_HIP_CHECK(hipGetLastError());                                                            \
     return GOAI_OK
 
@@ -841,6 +859,13 @@ int launch_sample(int S_rt, const Tree& t, const double* pi, uint64_t seed, uint
 {
     LAUNCH_PER_GAME(k_sample, t, pi, seed, step, game_offset, actions);
 }
+int launch_sample_keyed(int S_rt, const double* pi, uint64_t seed, const uint64_t* game_ids, const int32_t* steps, int n,
+                        int32_t* actions, hipStream_t st)
+{
+    GOAI_DISPATCH_SIZE(S_rt, k_sample_keyed<S><<<dim3((n + 63) / 64), dim3(64), 0, st>>>(pi, seed, game_ids, steps, n, actions));
+    GOAI_HIP_CHECK(hipGetLastError());
+    return GOAI_OK;
+}
 int launch_mcts_advance(int S_rt, const Tree& t, const int32_t* actions, int max_moves, hipStream_t st)
 {
     LAUNCH_PER_GAME(k_mcts_advance, t, actions, max_moves);
@@ -864,7 +889,7 @@ int launch_q_scan(const Tree& t, hipStream_t st)
 }
 int launch_q_expand(int S_rt, const Tree& t, uint8_t* children_out, uint8_t* valid_out, hipStream_t st)
 {
-    const long units = (long)t.n_games * (S_rt * S_rt + 1);
+    const long units = (long)t.n_active * (S_rt * S_rt + 1);
     const int grid = (int)(units < 262144 ? units : 262144);
     GOAI_DISPATCH_SIZE(S_rt, k_q_expand<S><<<dim3(grid), dim3(64), 0, st>>>(t, children_out, valid_out));
     GOAI_HIP_CHECK(hipGetLastError());

@@ -57,6 +57,8 @@ _SIGNATURES = {
     "goai_uniform_policy": [c_void_p, c_int, c_void_p],
     "goai_sample_actions": [c_void_p, c_void_p, c_uint64, c_uint64, c_int, c_void_p],
     "goai_mcts_advance": [c_void_p, c_void_p],
+    "goai_mcts_set_active": [c_void_p, c_int],
+    "goai_sample_actions_keyed": [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_int, c_void_p],
     "goai_mcts_node_capacity": [c_void_p],
     "goai_mcts_export_tree": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "goai_mcts_set_refill": [c_void_p, c_int],

@@ -182,6 +182,23 @@ class Context:
         self._bind()
         _hip.check(_hip.lib.goai_mcts_init(self._h, int(n_games), int(max_sims), int(mode)))
         self.n_games, self.max_sims, self.search_mode = int(n_games), int(max_sims), int(mode)
+        self.capacity = int(n_games)
+
+    def mcts_set_active(self, n_active):
+        """Work on the first n_active games only (goai_mcts_set_active); mcts_reset must follow."""
+        _hip.check(_hip.lib.goai_mcts_set_active(self._h, int(n_active)))
+        self.n_games = int(n_active)
+
+    def sample_actions_keyed(self, pi, seed, game_ids, steps):
+        """One draw per row of pi with the Philox key (seed, game_ids[i], steps[i])."""
+        self._bind()
+        n = pi.shape[0]
+        ids = torch.as_tensor(game_ids).to(self.device, dtype=torch.int64).contiguous()
+        st = torch.as_tensor(steps).to(self.device, dtype=torch.int32).contiguous()
+        actions = torch.empty(n, dtype=torch.int32, device=self.device)
+        _hip.check(_hip.lib.goai_sample_actions_keyed(self._h, _hip.ptr(pi), int(seed), _hip.ptr(ids), _hip.ptr(st), n,
+                                                      _hip.ptr(actions)))
+        return actions
 
     def mcts_reset(self, root_states):
         self._bind()

@@ -301,6 +301,180 @@ class BatchedSelfPlay:
         return ms, n
 
 
+class BatchedPlay:
+    """`play_games(go_env, first_policy, second_policy, episodes)` (/root/reference/go_ai/game.py:120-154) with
+    the episodes played `slots` at a time on the GPU: the first policy takes black in the even-numbered
+    episodes and white in the odd-numbered ones (game.py:141-146, episodes count from 1), a slot whose game
+    ends takes the next episode at once, and `first_wins`, `black_wins` and the step counts are accumulated
+    as the reference's loop does (game.py:147-149).  This is what evaluation needs
+    (/root/reference/train.py:13-20: a checkpoint against an older one, the random and the greedy player).
+
+    Every move, the running games are split by the policy that is to move (game.py:85-89); each policy's own
+    context searches its share as one batch (goai_mcts_set_active / goai_mcts_reset / goai_mcts_run), turns the
+    result into pi (goai_mcts_policy / goai_mcts_policy_value) and draws the action with the Philox key
+    (seed, episode number, move number) -- a game does not depend on the slot, the batch or the GPU it is played
+    in.  The moves themselves are goai_transition / goai_score on the whole batch.
+
+    Policies: go_ai.policies.ActorCritic (mcts > 0: actor-critic search; mcts == 0: the critic's child values),
+    go_ai.policies.Value (Q-value search, or child values for mcts == 0) on go_ai.models nets, and
+    go_ai.policies.baselines.Random."""
+
+    def __init__(self, size, first_policy, second_policy, slots=256, device=0, seed=1234, episode_offset=0):
+        self.size, self.slots, self.seed, self.episode_offset = size, int(slots), seed, int(episode_offset)
+        self.P, self.A = size * size, size * size + 1
+        self.device = torch.device("cuda", device)
+        self.policies = [self._prepare(first_policy, device), self._prepare(second_policy, device)]
+        self.rules = Context(size, device)
+        self._record = False
+
+    def _prepare(self, policy, device):
+        from .policies.actorcritic import ActorCritic
+        from .policies.baselines import Random
+        from .policies.value import Value
+        if isinstance(policy, Random):
+            c = Context(self.size, device)
+            c.mcts_init(self.slots, 0)
+            return dict(kind="random", ctx=c, policy=policy)
+        net = getattr(policy, "pt_model", None)
+        if net is None and isinstance(policy, Value):
+            from .policies import baselines
+            batched = {baselines.greedy_val_func: self._greedy_values, baselines.smart_greedy_val_func: self._smart_greedy_values}
+            if policy.val_func in batched:
+                c = Context(self.size, device)
+                c.mcts_init(self.slots, max(policy.mcts, 0), Context.SEARCH_Q)
+                return dict(kind="valfunc", ctx=c, policy=policy, values=batched[policy.val_func])
+        if net is None or not hasattr(net, "search_context"):
+            raise TypeError(f"BatchedPlay needs policies on go_ai.models nets (or baselines' Random / greedy players), got {policy}")
+        if isinstance(policy, ActorCritic) and policy.mcts > 0:
+            kind, mode = "ac", Context.SEARCH_AC
+        elif isinstance(policy, (ActorCritic, Value)) and policy.mcts >= 0:
+            kind, mode = "q", Context.SEARCH_Q
+        else:
+            raise TypeError(f"unsupported policy for batched play: {policy}")
+        return dict(kind=kind, ctx=net.search_context(self.slots, max(policy.mcts, 0), mode), policy=policy)
+
+    # baselines.greedy_val_func / smart_greedy_val_func (/root/reference/go_ai/policies/baselines.py:11-55) on device tensors
+    def _greedy_values(self, states):
+        b, w, ended, _ = self.rules.score(states)
+        d = (b - w).to(torch.float64)
+        return torch.where(ended > 0, 100.0 * torch.sign(d), d / self.P)
+
+    def _smart_greedy_values(self, states):
+        b, w, ended, _ = self.rules.score(states)
+        bl, wl = self.rules.liberties(states)
+        area = (b - w).to(torch.float64) / self.P
+        libs = (bl - wl).to(torch.float64) / self.P
+        return torch.where(ended > 0, torch.sign(area), (6 * area + libs) / 7)
+
+    def record(self, on=True):
+        """Keep every move so that play() also returns the reference's Trajectory objects."""
+        self._record = bool(on)
+
+    def _pi(self, pol, states):
+        """pi of one policy for `states` (k canonical roots on the GPU), as a device tensor [k, A]."""
+        c = pol["ctx"]
+        k = states.shape[0]
+        c.mcts_set_active(k)
+        c.mcts_reset(states)
+        if pol["kind"] == "random":
+            return c.uniform_policy(allow_pass=True)
+        policy = pol["policy"]
+        if pol["kind"] == "valfunc":
+            # mct_step with a value function that is not a network (mct.py:27-30,43-47): the kernels hand out the
+            # leaf and its children, the function values them (here: area / liberty counts by the rule kernels)
+            for _ in range(max(policy.mcts, 0) + 1):
+                leaves = c.mcts_select()
+                kids, _ = c.mcts_expand()
+                c.mcts_backup_q(pol["values"](leaves), pol["values"](kids.reshape(k * self.A, 6, self.size, self.size)).reshape(k, self.A))
+            return c.mcts_policy_value(policy.temp, from_values=(policy.mcts == 0))
+        c.mcts_run(max(policy.mcts, 0))
+        if pol["kind"] == "ac":
+            return c.mcts_policy(policy.temp)
+        return c.mcts_policy_value(policy.temp, from_values=(policy.mcts == 0))
+
+    def play(self, episodes):
+        """Returns (first_wins / episodes, black_wins / episodes, replay, all_steps) like play_games
+        (game.py:154); replay is a list of Trajectory (empty unless record() was called), all_steps the
+        number of moves of every episode, both in episode order.  Also sets self.results:
+        per episode (black_won, first_won, steps)."""
+        S, P, dev = self.size, self.P, self.device
+        n = min(self.slots, episodes)
+        max_steps = 2 * P                                            # game.py:74
+        states = torch.zeros((n, 6, S, S), dtype=torch.uint8, device=dev)
+        turn = torch.zeros(n, dtype=torch.int64, device=dev)         # 0 black to move
+        moves = torch.zeros(n, dtype=torch.int64, device=dev)
+        episode = torch.arange(1, n + 1, dtype=torch.int64, device=dev)     # 1-based, as the reference counts
+        active = torch.ones(n, dtype=torch.bool, device=dev)
+        next_episode = n + 1
+        black_won = np.zeros(episodes + 1, dtype=np.int64)
+        steps = np.zeros(episodes + 1, dtype=np.int64)
+        trajs = {i: Trajectory() for i in range(1, episodes + 1)} if self._record else None
+        self.leaf_evals = 0
+        while bool(active.any()):
+            idx = active.nonzero().flatten()
+            # the first policy is black in even episodes (game.py:141-146); who moves now?
+            first_is_black = (episode[idx] % 2 == 0)
+            mover = torch.where(first_is_black == (turn[idx] == 0), 0, 1)
+            actions = torch.empty(len(idx), dtype=torch.int32, device=dev)
+            pis = torch.empty((len(idx), self.A), dtype=torch.float64, device=dev) if self._record else None
+            for which in (0, 1):
+                sel = (mover == which).nonzero().flatten()
+                if len(sel) == 0:
+                    continue
+                sub = idx[sel]
+                pol = self.policies[which]
+                pi = self._pi(pol, states[sub].contiguous())
+                acts = pol["ctx"].sample_actions_keyed(pi, self.seed, episode[sub] + self.episode_offset, moves[sub])
+                actions[sel] = acts
+                if pis is not None:
+                    pis[sel] = pi
+                if pol["kind"] != "random":
+                    self.leaf_evals += len(sel) * (max(pol["policy"].mcts, 0) + 1)
+            cur = states[idx].contiguous()
+            nxt, status = self.rules.transition(cur, actions, canonical=True)
+            assert bool((status == 0).all()), "a policy chose an illegal move"
+            if self._record:
+                kids = self.rules.children(cur, canonical=True)[0].cpu().numpy().astype(np.float64)
+                cur_h, pis_h, acts_h, turn_h, ep_h = cur.cpu().numpy(), pis.cpu().numpy(), actions.cpu().numpy(), \
+                    turn[idx].cpu().numpy(), episode[idx].cpu().numpy()
+                for j in range(len(idx)):
+                    t = trajs[int(ep_h[j])]
+                    t.add_event(cur_h[j].astype(np.float64), int(acts_h[j]), 0.0, kids[j], pis_h[j])
+                    if t.movers is None:
+                        t.movers = []
+                    t.movers.append(int(turn_h[j]))
+            states[idx] = nxt
+            turn[idx] ^= 1
+            moves[idx] += 1
+            over = (nxt[:, 5, 0, 0] != 0) | (moves[idx] > max_steps)          # two passes, or the step cap (game.py:97-99)
+            if bool(over.any()):
+                fin = idx[over]
+                b, w, _, _ = self.rules.score(states[fin].contiguous())
+                sign = torch.sign(b - w).to(torch.int64)                       # canonical frame: plane 0 = the side to move
+                res = torch.where(turn[fin] == 1, -sign, sign).cpu().numpy()   # black's result (go_env.winning(), game.py:113)
+                ep_h, mv_h = episode[fin].cpu().numpy(), moves[fin].cpu().numpy()
+                for j, e in enumerate(ep_h):
+                    black_won[e], steps[e] = res[j], mv_h[j]
+                    if trajs is not None:
+                        trajs[int(e)].set_win(int(res[j]))
+                # the slot takes the next episode, if any is left
+                for slot in fin.tolist():
+                    if next_episode <= episodes:
+                        states[slot] = 0
+                        turn[slot] = 0
+                        moves[slot] = 0
+                        episode[slot] = next_episode
+                        next_episode += 1
+                    else:
+                        active[slot] = False
+        eps = np.arange(1, episodes + 1)
+        first_won = np.where(eps % 2 == 0, black_won[1:], -black_won[1:])
+        self.results = dict(black_won=black_won[1:].copy(), first_won=first_won, steps=steps[1:].copy())
+        replay = [trajs[i] for i in range(1, episodes + 1)] if trajs is not None else []
+        return float((first_won == 1).sum()) / episodes, float((black_won[1:] == 1).sum()) / episodes, replay, \
+            [int(x) for x in steps[1:]]
+
+
 from .sharding import STAT_FIELDS, gather_stats, reduce_stats, shard_games  # noqa: E402,F401
 
 

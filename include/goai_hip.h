@@ -260,6 +260,18 @@ int goai_sample_actions(goai_ctx* ctx, const double* pi, uint64_t seed, uint64_t
  * mct.py:52-53).  A game ends after two passes or more than 2*S*S moves (game.py:74,98). */
 int goai_mcts_advance(goai_ctx* ctx, const int32_t* actions);
 
+/* Work on the first n_active <= n_games games only until further notice (default: all).  For callers that own
+ * the games and give a context a different subset every move -- two policies playing each other, where each
+ * policy's context searches the games in which it is to move (/root/reference/go_ai/game.py:80-89).  Every
+ * array argument of the search calls then has n_active rows; goai_mcts_reset must follow. */
+int goai_mcts_set_active(goai_ctx* ctx, int n_active);
+
+/* goai_sample_actions with the Philox key given per row: row i draws from pi[i] with key
+ * (seed, game_ids[i], steps[i]) -- the game's own id and move number, so a game's draws do not depend on
+ * which slot, context or GPU it is played in.  Needs no search state. */
+int goai_sample_actions_keyed(goai_ctx* ctx, const double* pi, uint64_t seed, const uint64_t* game_ids,
+                              const int32_t* steps, int n, int32_t* actions);
+
 /* The whole search tree of one game, for host-side views of tree.Node (/root/reference/go_ai/search/tree.py:22-52;
  * what policy(go_env, debug=True) hands to search/plot.py:39-61).  Node n < *n_nodes (all device arrays sized
  * goai_mcts_node_capacity()): parent[n] (-1 for the root, node 0), action[n] = the move that led to it,

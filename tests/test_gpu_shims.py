@@ -403,3 +403,88 @@ def test_q_helpers_and_replay_conversions_match_oracle():
     assert cols[0].shape == (len(events), 6, 5, 5) and cols[0].dtype == np.float32
     assert cols[3].shape == (len(events), 26, 6, 5, 5) and cols[4].dtype == np.uint8 and cols[6].shape == (len(events), 26)
     assert data.events_to_numpy([]) == ([], [], [], [], [], [])
+
+
+def test_batched_play_two_policies_matches_sequential_oracle():
+    """go_ai.game.BatchedPlay = play_games(go_env, first, second, episodes) (game.py:120-154) on the GPU: colours alternate
+    by episode, results are accumulated as the reference does, and every recorded move is what the sequential oracle
+    search computes for the policy that was to move, fed that policy's own network (pi bit for bit), with the action
+    the Philox stream drew; winner and step count by the oracle's rules.  Results do not depend on the slot count."""
+    import types
+    from go_ai.game import BatchedPlay
+    from go_ai.models.ac_net import ActorCriticNet
+    from go_ai.models.val_net import ValueNet
+    from go_ai.policies.actorcritic import ActorCritic
+    from go_ai.policies.value import Value
+    from oracle import mcts_ref
+    from oracle.gogame import GoEnv as OEnv, GoGame as OG
+    size, episodes = 5, 10
+    net_a, net_b = ActorCriticNet(size, max_batch=64), ValueNet(size, max_batch=64)
+    net_a.load_state_dict(nn_ref.make_state_dict("ac", size, 3))
+    net_b.load_state_dict(nn_ref.make_state_dict("val", size, 4))
+    first = ActorCritic("a", net_a, types.SimpleNamespace(temp=1, mcts=6))
+    second = Value("b", net_b, types.SimpleNamespace(temp=1, mcts=3))
+    runs = []
+    for slots in (4, 16):
+        bp = BatchedPlay(size, first, second, slots=slots, seed=7)
+        bp.record()
+        fw, bw, replay, steps = bp.play(episodes)
+        runs.append((fw, bw, steps, bp.results, replay))
+    fw, bw, steps, res, replay = runs[0]
+    assert runs[1][0] == fw and runs[1][1] == bw and runs[1][2] == steps          # slot count does not matter
+    assert all(np.array_equal(a.actions, b.actions) and all(np.array_equal(x, y) for x, y in zip(a.pis, b.pis))
+               for a, b in zip(replay, runs[1][4]))
+    assert len(replay) == episodes and [len(t) for t in replay] == steps
+    assert fw == (res["first_won"] == 1).mean() and bw == (res["black_won"] == 1).mean()
+
+    ac_fn, val_fn = net_a.create_numpy('actor_critic'), net_b.create_numpy('critic')
+    for e, traj in enumerate(replay, start=1):
+        first_is_black = e % 2 == 0                                              # game.py:141-146
+        env = OEnv(size)
+        env.reset()
+        assert traj.movers == [i % 2 for i in range(len(traj))]
+        for i in range(len(traj)):
+            assert np.array_equal(traj.states[i], env.canonical_state())
+            mover_is_first = (traj.movers[i] == 0) == first_is_black
+            if mover_is_first:
+                pi, _, _ = mcts_ref.actor_critic_policy(env, ac_fn, 6, 1.0, math="det")
+            else:
+                pi, _ = mcts_ref.value_policy(env, val_fn, 3, 1.0, math="det")
+            assert np.array_equal(pi, traj.pis[i]), (e, i, np.abs(pi - traj.pis[i]).max())
+            assert pi[traj.actions[i]] > 0
+            assert np.array_equal(traj.children[i], np.asarray(OG.children(env.canonical_state(), canonical=True, padded=True)))
+            _, _, done, _ = env.step(traj.actions[i])
+            assert done == (i == len(traj) - 1) or len(traj) == 2 * size * size + 1
+        assert env.winning() == res["black_won"][e - 1] == traj.get_winner()
+        assert res["first_won"][e - 1] == (res["black_won"][e - 1] if first_is_black else -res["black_won"][e - 1])
+        assert steps[e - 1] == len(traj) <= 2 * size * size + 1
+
+
+def test_batched_play_against_random_and_greedy():
+    """The evaluation opponents of /root/reference/train.py:13-20: baselines.Random and the greedy player
+    (Value on baselines.greedy_val_func, mcts = 0) in batched play; the greedy player's pi equals the host policy's."""
+    import types
+    from go_ai.env import GoEnv
+    from go_ai.game import BatchedPlay
+    from go_ai.models.ac_net import ActorCriticNet
+    from go_ai.policies import baselines
+    from go_ai.policies.actorcritic import ActorCritic
+    from go_ai.policies.value import Value
+    size = 5
+    net = ActorCriticNet(size, max_batch=64)
+    ac = ActorCritic("a", net, types.SimpleNamespace(temp=1, mcts=4))
+    greedy = Value('Greedy', baselines.greedy_val_func, types.SimpleNamespace(temp=1, mcts=0))
+    bp = BatchedPlay(size, ac, baselines.Random(), slots=8, seed=1)
+    fw, bw, _, steps = bp.play(12)
+    assert 0 <= fw <= 1 and len(steps) == 12 and all(2 <= s <= 51 for s in steps)
+    bp = BatchedPlay(size, greedy, baselines.Random(), slots=8, seed=2)
+    bp.record()
+    fw, bw, replay, steps = bp.play(6)
+    assert fw >= 0.5                                   # greedy area-grabbing beats uniform random play
+    for e, traj in enumerate(replay, start=1):
+        greedy_is_black = e % 2 == 0
+        for i in range(min(len(traj), 6)):
+            if (traj.movers[i] == 0) == greedy_is_black:
+                env = GoEnv(size)
+                env.state = traj.states[i].copy()      # canonical: the mover is "black"
+                assert np.allclose(greedy(env), traj.pis[i], rtol=1e-12, atol=0)
