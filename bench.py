@@ -242,7 +242,7 @@ def main():
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if args.dtype == "auto":
-        args.dtype = "bf16x6" if cfg["size"] == 9 else "f32"
+        args.dtype = "bf16x6"
     global SIZE, SIMS, LAYERS
     SIZE, SIMS, LAYERS = cfg["size"], cfg["sims"], cfg["layers"]
 
@@ -310,7 +310,7 @@ def main():
     peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     algo = sp.ctx.nn_conv_algo()
     kname = {0: "k_conv3x3", 1: "k_conv3x3_wino", 2: "k_conv3x3_bf16", 3: "k_conv3x3_wino3", 4: "k_conv3x3_wino3p",
-             5: "k_conv3x3_wino3s"}[algo] + f"<{SIZE}>"
+             5: "k_conv3x3_wino3s", 6: "k_conv3x3_wino2s"}[algo] + f"<{SIZE}>"
     executed_flop = conv_flop                 # flops the matrix pipe really executes per launch
     if algo == 2:
         executed_flop = 3.0 * conv_flop       # hi*hi + lo*hi + hi*lo on the bf16 pipe
@@ -321,6 +321,12 @@ def main():
         wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // (112 // t2))
         rows = 100 if SIZE in (9, 13, 19) else 112       # six 16-row tiles + one round of 4x4 blocks, or seven tiles
         executed_flop = 2.0 * wgs * rows * 16 * 128 * 128
+    elif algo == 6:
+        # Winograd F(2x2,3x3) on the bf16 pipe: workgroups of seven 16-column tiles (112 wtile rows), 16 positions, six
+        # bf16 products per transform-domain multiply-add
+        t2 = ((SIZE + 1) // 2) ** 2
+        wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // (112 // t2))
+        executed_flop = 6 * 2.0 * wgs * 112 * 16 * 128 * 128
     elif algo == 5:
         # Winograd F(3x3,3x3) on the bf16 pipe: 4 boards = 36 wtile rows run as three 16-column tiles, six
         # bf16 products (three-way split operands) per transform-domain multiply-add
@@ -384,6 +390,8 @@ def main():
                                        2: "direct implicit GEMM, bf16 MFMA on hi+lo split operands (3 products per multiply-add)",
                                        3: "Winograd F(3x3,3x3), fp32 MFMA",
                                        4: "Winograd F(3x3,3x3), fp32 MFMA (16x16x4 + 4x4x1), two 32-channel chunks per output transform",
+                                       6: "Winograd F(2x2,3x3), bf16 MFMA 16x16x32 on operands split exactly into three bf16 parts "
+                                          "(6 products per multiply-add, fp32 accumulate, fp32 transforms): fp32-grade results",
                                        5: "Winograd F(3x3,3x3), bf16 MFMA 16x16x32 on operands split exactly into three bf16 parts "
                                           "(6 products per multiply-add, fp32 accumulate, fp32 transforms): fp32-grade results"}[algo],
                          "algorithmic_flop_per_launch": conv_flop,

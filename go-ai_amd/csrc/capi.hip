@@ -129,7 +129,7 @@ int goai_nn_conv_algo(goai_ctx* ctx)
     GOAI_REQUIRE(ctx, "ctx is NULL");
     GOAI_REQUIRE(ctx->net.kind >= 0, "call goai_nn_init first");
     if (ctx->net.dtype == GOAI_DTYPE_BF16X3) return GOAI_CONV_BF16X3;
-    if (ctx->net.split6) return GOAI_CONV_WINOGRAD_F3_BF16X6;
+    if (ctx->net.split6) return ctx->net.wino_mode == 3 ? GOAI_CONV_WINOGRAD_F3_BF16X6 : GOAI_CONV_WINOGRAD_BF16X6;
     if (ctx->net.wino_mode == 3) return ctx->net.wino3_paired ? GOAI_CONV_WINOGRAD_F3_PAIRED : GOAI_CONV_WINOGRAD_F3;
     return ctx->net.wino_mode ? GOAI_CONV_WINOGRAD : GOAI_CONV_DIRECT;
 }

@@ -1,0 +1,289 @@
+// conv_wino2s_kernels.hip -- the trunk's conv3x3 128 -> 128 (+ folded BatchNorm bias, optional residual,
+// ReLU; /root/reference/go_ai/models/__init__.py:234-251) by Winograd F(2x2,3x3) with its 16
+// transform-domain GEMMs on the BF16 matrix cores, every fp32 operand split EXACTLY into three bf16
+// parts (GOAI_DTYPE_BF16X6 on boards other than 9x9; the 9x9 form is conv_wino3s_kernels.hip, which
+// explains the arithmetic: U V = u0 v0 + (u0 v1 + u1 v0) + (u0 v2 + u1 v1 + u2 v0) + terms below 2^-24).
+//
+// Decomposition = conv_wino_kernels.hip: a workgroup (8 waves) owns NBW whole boards = NBW * T*T wtiles of
+// 2x2 outputs (13x13: 2 boards = 98 wtiles, 19x19: 1 board = 100), at most 112 = seven 16-column MFMA tiles,
+// and all 128 output channels; wave w owns output channels 16w .. 16w+15.  Loop: 4 channel chunks x 4
+// transform rows p; per row one input-transform phase (all threads; Bt d B in fp32 on the vector ALUs, then
+// the three-way split) and 4 stages q of 7 tiles x 6 bf16 MFMAs (K = 32) per wave, each followed by the
+// fp32 output transform of its products.
+// LDS: IMG  one 32-channel chunk of the boards, fp32, [NBW * P cells + a zero cell][32 ch] (46 KB at 19x19)
+//      V    [4 q][3 parts][112 rows][32 ch] bf16 = 86 KB, single-buffered
+//      Tab  16 cell addresses per wtile
+// Weights: [64 stages][8 waves][3 parts][64 lanes][8 bf16] per convolution (nn_host.hip), L2 -> registers one
+// stage ahead into alternating register sets; V fragments are read one tile ahead.
+#include "go_board.h"
+#include "goai_internal.h"
+#include "nn.h"
+
+namespace goai {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int S>
+struct Wino2S {
+    static constexpr int T = (S + 1) / 2, T2 = T * T, P = S * S;
+    static constexpr int MT = 7, ROWS = MT * 16;                   // wtile rows per workgroup
+    static constexpr int NBW = ROWS / T2;                          // whole boards per workgroup
+    static constexpr int WT = NBW * T2;                            // real wtiles per workgroup
+    static constexpr int IMG_U4 = NBW * P * 8 + 8;                 // in 16-byte units (+ the zero cell)
+    static constexpr int ZERO_U4 = NBW * P * 8;
+    static constexpr int V_PART_U4 = ROWS * 4;                     // one (q, part): [ROWS][32 ch] bf16 = 64 B per row
+    static constexpr int V_U4 = 4 * 3 * V_PART_U4;
+    static constexpr int TAB_U4 = WT * 2;                          // 16 x u16 LDS addresses per wtile
+    static constexpr int NI = (NBW * P * 8 + 511) / 512;           // staged 16-byte pieces per thread per chunk
+    static constexpr int LDS_U4 = IMG_U4 + V_U4 + TAB_U4;
+    static_assert(NBW >= 1, "board too large for one workgroup");
+    static_assert(LDS_U4 * 16 <= 160 * 1024, "LDS budget");
+    static_assert(IMG_U4 * 16 < 65536, "input-transform addresses are 16-bit");
+};
+
+__device__ __forceinline__ int w2s_swz(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
+// two fp32 bit patterns whose low halves are dropped -> one word of two bf16 (a in the low half)
+__device__ __forceinline__ unsigned w2s_pack(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+template <int S, bool RESID>
+__global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict__ in, const uint4* wt,
+                                                        const float* __restrict__ bias,
+                                                        const float* __restrict__ resid, float* __restrict__ out,
+                                                        int nboards)
+{
+    using W = Wino2S<S>;
+    constexpr int P = W::P, MT = W::MT;
+    __shared__ f32x4 lds[W::LDS_U4];
+    f32x4* Img = lds;
+    f32x4* Vs = lds + W::IMG_U4;
+    uint16_t* Tab = reinterpret_cast<uint16_t*>(lds + W::IMG_U4 + W::V_U4);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int b_first = blockIdx.x * W::NBW;
+
+    // V rows WT..ROWS-1 are never written: they stay zero and only reach accumulator columns that are never stored
+    for (int i = tid; i < W::V_U4; i += 512) Vs[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    if (tid < 8) Img[W::ZERO_U4 + tid] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    // Tab[tw][a][b] = byte address in Img (slot 0, before the slot swizzle) of cell (2ty - 1 + a, 2tx - 1 + b) of
+    // wtile tw's 4x4 input patch, or of the zero cell when that is off the board
+    for (int e = tid; e < W::WT * 16; e += 512) {
+        const int tw = e >> 4, a = (e >> 2) & 3, b = e & 3;
+        const int bl = tw / W::T2, rem = tw - bl * W::T2;
+        const int ty = rem / W::T, tx = rem - ty * W::T;
+        const int y = 2 * ty - 1 + a, x = 2 * tx - 1 + b;
+        const bool ok = y >= 0 && y < S && x >= 0 && x < S;
+        Tab[e] = (uint16_t)((ok ? (bl * P + y * S + x) * 8 : W::ZERO_U4) * 16);
+    }
+
+    const int ts = tid & 7;                           // 4-channel slot of this thread's input-transform items
+    f32x4 ireg[W::NI];
+    auto load_img = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < W::NI; i++) {
+            const int idx = tid + i * 512;
+            const int cr = idx >> 3, slot = idx & 7;
+            const int board = b_first + cr / P;
+            f32x4 v = { 0.0f, 0.0f, 0.0f, 0.0f };
+            if (idx < W::NBW * P * 8 && board < nboards)
+                v = *reinterpret_cast<const f32x4*>(&in[((long)b_first * P + cr) * 128 + chunk * 32 + slot * 4]);
+            ireg[i] = v;
+        }
+    };
+    auto store_img = [&]() {
+#pragma unroll
+        for (int i = 0; i < W::NI; i++) {
+            const int idx = tid + i * 512;
+            if (idx < W::NBW * P * 8) Img[w2s_swz(idx >> 3, idx & 7)] = ireg[i];
+        }
+    };
+    auto img_at = [&](uint32_t byte_addr) -> f32x4 {
+        const uint32_t cell = byte_addr >> 7;         // slot swizzle of w2s_swz() on a byte address
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Img) + byte_addr +
+                                               ((ts ^ ((cell >> 1) & 7)) << 4));
+    };
+    // V[q][part][tw][ts] = the three bf16 parts of (Bt d B)[p][q], q = 0..3; rows of Bt are
+    // (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
+    auto transform = [&](int p) {
+        const int a1 = (p == 0) ? 0 : 1, a2 = (p == 3) ? 3 : 2;
+        const float s1 = (p == 2) ? -1.0f : 1.0f, s2 = (p == 0 || p == 3) ? -1.0f : 1.0f;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int tw = (tid >> 3) + 64 * j;
+            if (tw >= W::WT) continue;
+            const uint2 t1 = *reinterpret_cast<const uint2*>(&Tab[tw * 16 + a1 * 4]);
+            const uint2 t2 = *reinterpret_cast<const uint2*>(&Tab[tw * 16 + a2 * 4]);
+            f32x4 r[4];
+            r[0] = s1 * img_at(t1.x & 0xffffu) + s2 * img_at(t2.x & 0xffffu);
+            r[1] = s1 * img_at(t1.x >> 16) + s2 * img_at(t2.x >> 16);
+            r[2] = s1 * img_at(t1.y & 0xffffu) + s2 * img_at(t2.y & 0xffffu);
+            r[3] = s1 * img_at(t1.y >> 16) + s2 * img_at(t2.y >> 16);
+            uint2* V = reinterpret_cast<uint2*>(Vs) + tw * 8 + ts;
+            auto put = [&](int q, const f32x4 v) {
+                unsigned h[4], m[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    h[e] = __float_as_uint(v[e]) & 0xffff0000u;
+                    const float r1 = v[e] - __uint_as_float(h[e]);
+                    m[e] = __float_as_uint(r1) & 0xffff0000u;
+                    l[e] = __float_as_uint(r1 - __uint_as_float(m[e]));      // <= 8 significant bits: its low half is zero
+                }
+                uint2* dst = V + q * (3 * W::V_PART_U4 * 2);
+                dst[0] = uint2{ w2s_pack(h[0], h[1]), w2s_pack(h[2], h[3]) };
+                dst[W::V_PART_U4 * 2] = uint2{ w2s_pack(m[0], m[1]), w2s_pack(m[2], m[3]) };
+                dst[2 * W::V_PART_U4 * 2] = uint2{ w2s_pack(l[0], l[1]), w2s_pack(l[2], l[3]) };
+            };
+            put(0, r[0] - r[2]);
+            put(1, r[1] + r[2]);
+            put(2, r[2] - r[1]);
+            put(3, r[1] - r[3]);
+        }
+    };
+
+    // weights of a stage: the three bf16 parts of U[stage = (chunk * 4 + p) * 4 + q] in the lanes' own order:
+    // lane (li, lq) gets output channel 16 wave + li, input channels 8 lq .. 8 lq + 7 of the chunk
+    const uint4* wsrc = wt + wave * 192 + lane;       // [stage][wave][part][lane] x 16 B
+    u32x4 wf[2][3];
+    auto load_b = [&](int stage, u32x4* b) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(wsrc + (size_t)stage * (8 * 192));
+        b[0] = src[0];
+        b[1] = src[64];
+        b[2] = src[128];
+        // keep the load where it is written (the optimiser would sink it to the loop's end, in front of its use;
+        // wt is deliberately not __restrict__: loads from a noalias pointer may cross this fence)
+        asm volatile("" ::: "memory");
+    };
+    auto v_read = [&](int q, int t, uint4* v) {
+        const uint4* V = reinterpret_cast<const uint4*>(Vs) + (q * 3) * W::V_PART_U4 + (t * 16 + li) * 4 + lq;
+#pragma unroll
+        for (int r = 0; r < 3; r++) v[r] = V[r * W::V_PART_U4];
+    };
+
+    f32x4 Y[2][2][MT];                               // [i][j]: output (2ty + i, 2tx + j) of the wtile
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int t = 0; t < MT; t++) Y[i][j][t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+
+    load_img(0);
+    load_b(0, wf[0]);
+    __syncthreads();                                 // the zero fills and the table are complete
+    store_img();
+
+#pragma unroll 1
+    for (int chunk = 0; chunk < 4; chunk++) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            __syncthreads();                         // the image is staged; every wave has read the previous row of V
+            if (p == 2 && chunk + 1 < 4) load_img(chunk + 1);      // in flight during this row
+            transform(p);
+            __syncthreads();                         // V complete; (p == 3) the image is dead
+            if (p == 3 && chunk + 1 < 4) store_img();
+            uint4 vf[2][3];                          // (plain words: a bf16 vector across a branch is re-packed element-wise)
+            v_read(0, 0, vf[0]);
+#pragma unroll 1
+            for (int q2 = 0; q2 < 2; q2++) {
+                // two stages per trip: the weight sets and the fragment ring (14 tile steps) come out even
+#pragma unroll
+                for (int qq = 0; qq < 2; qq++) {
+                    const int q = 2 * q2 + qq;
+                    const int s = chunk * 16 + p * 4 + q;
+                    load_b(s + 1 < 64 ? s + 1 : 63, wf[(qq + 1) & 1]);   // unconditional: the wait counts stay exact
+                    const bf16x8 u0 = __builtin_bit_cast(bf16x8, wf[qq][0]), u1 = __builtin_bit_cast(bf16x8, wf[qq][1]),
+                                 u2 = __builtin_bit_cast(bf16x8, wf[qq][2]);
+                    f32x4 m[MT];
+#pragma unroll
+                    for (int t = 0; t < MT; t++) {
+                        const int n = qq * MT + t;   // tile step of the trip; its fragments sit in vf[n & 1]
+                        if (t + 1 < MT) v_read(q, t + 1, vf[(n + 1) & 1]);
+                        else v_read(q < 3 ? q + 1 : 3, 0, vf[(n + 1) & 1]);          // (q == 3: a harmless re-read)
+                        const bf16x8 v[3] = { __builtin_bit_cast(bf16x8, vf[n & 1][0]), __builtin_bit_cast(bf16x8, vf[n & 1][1]),
+                                              __builtin_bit_cast(bf16x8, vf[n & 1][2]) };
+                        // the six products of weight up to 2^-16, smallest first
+                        f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u2, v[0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, v[1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, v[0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[1], acc, 0, 0, 0);
+                        m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[0], acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);             // keep the pipeline as written
+                    }
+                    // output transform: Y[i][j] += At[i][p] * At[j][q] * M,  At = (1 1 1 0 ; 0 1 -1 -1); p is unrolled
+                    // (compile-time row factor), q is a run-time value (column factor as +-1.0 / 0)
+                    const float cj0 = (q < 3) ? 1.0f : 0.0f;
+                    const float cj1 = (q == 0) ? 0.0f : (q == 1 ? 1.0f : -1.0f);
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        const int ci = (i == 0) ? (p < 3 ? 1 : 0) : (p == 0 ? 0 : (p == 1 ? 1 : -1));
+                        if (ci != 0) {
+                            const float f0 = ci > 0 ? cj0 : -cj0, f1 = ci > 0 ? cj1 : -cj1;
+#pragma unroll
+                            for (int t = 0; t < MT; t++)
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    Y[i][0][t][e] = fmaf(f0, m[t][e], Y[i][0][t][e]);
+                                    Y[i][1][t][e] = fmaf(f1, m[t][e], Y[i][1][t][e]);
+                                }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+
+    // epilogue.  The products are formed transposed (A operand = weights, B operand = V), so in the C/D layout of
+    // a 16x16 tile (col = lane & 15, row = 4 * (lane >> 4) + reg) a lane holds FOUR CONSECUTIVE output channels
+    // of ONE wtile: one 16-byte load / store per output cell.
+    auto finish = [&](const f32x4 yv, const f32x4 bv, int y, int x, long board, int c0) {
+        if (y < S && x < S) {
+            const long off = (board * P + y * S + x) * 128 + c0;
+            f32x4 v = yv + bv;
+            if (RESID) v += *reinterpret_cast<const f32x4*>(&resid[off]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
+            *reinterpret_cast<f32x4*>(&out[off]) = v;
+        }
+    };
+    const int col = wave * 16 + 4 * lq;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col]);
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        const int w = t * 16 + li;
+        const int bl = w / W::T2, rem = w - bl * W::T2;
+        const long board = b_first + bl;
+        if (w >= W::WT || board >= nboards) continue;
+        const int ty = rem / W::T, tx = rem - ty * W::T;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) finish(Y[i][j][t], bv, 2 * ty + i, 2 * tx + j, board, col);
+    }
+}
+
+template <int S>
+static int launch_wino2s_size(const float* in, const void* wt_split, const float* bias, const float* resid, float* out,
+                              int nboards, hipStream_t st)
+{
+    const int grid = (nboards + Wino2S<S>::NBW - 1) / Wino2S<S>::NBW;
+    const uint4* wt = reinterpret_cast<const uint4*>(wt_split);
+    if (resid) k_conv3x3_wino2s<S, true><<<dim3(grid), dim3(512), 0, st>>>(in, wt, bias, resid, out, nboards);
+    else k_conv3x3_wino2s<S, false><<<dim3(grid), dim3(512), 0, st>>>(in, wt, bias, resid, out, nboards);
+    GOAI_HIP_CHECK(hipGetLastError());
+    return GOAI_OK;
+}
+
+// wt_split: [64 stages][8 waves][3 parts][64 lanes][8 bf16] of one convolution (nn_host.hip)
+int launch_conv3x3_wino2s(int S_rt, const float* in, const void* wt_split, const float* bias, const float* resid,
+                          float* out, int nboards, hipStream_t st)
+{
+    GOAI_DISPATCH_SIZE(S_rt, return launch_wino2s_size<S>(in, wt_split, bias, resid, out, nboards, st));
+    return GOAI_OK;
+}
+
+}  // namespace goai

@@ -36,7 +36,8 @@ struct Net {
     void* wino3_tab[2] = { nullptr, nullptr };   // input-transform address tables for 4 / 5 boards per workgroup
     int n_cu = 256;
     bool split6 = false;       // GOAI_DTYPE_BF16X6: F(3x3,3x3) with its products on the bf16 matrix cores, operands split in three
-    void* wt_split6 = nullptr; // [2*layers][100 stages][8 waves][3 parts][64 lanes][8 bf16] (conv_wino3s_kernels.hip)
+    void* wt_split6 = nullptr; // [2*layers][stages][8 waves][3 parts][64 lanes][8 bf16]: 100 stages for F(3x3,3x3) on 9x9
+                               // (conv_wino3s_kernels.hip), 64 for F(2x2,3x3) on the other boards (conv_wino2s_kernels.hip)
     void* wt_bf16 = nullptr;   // bf16x3: [2*layers][4 chunks][9 taps][128 out][32 hi | 32 lo]
     float* bt = nullptr;       // [2*layers][128]
     float* head_blob = nullptr;
@@ -64,6 +65,8 @@ int launch_conv3x3_wino3p(int S, float* x, float* y, const float* resid0, const 
                           const void* tab, int nboards, int n_cu, int n_convs, hipStream_t st);
 int launch_conv3x3_wino3s(int S, float* x, float* y, const float* resid0, const void* wt_split, const float* bias,
                           const void* tab, int nboards, int n_convs, hipStream_t st);
+int launch_conv3x3_wino2s(int S, const float* in, const void* wt_split, const float* bias, const float* resid, float* out,
+                          int nboards, hipStream_t st);
 int launch_conv3x3_wino(int S, const float* in, const float* wt_wino, const float* bias, const float* resid, float* out,
                         int nboards, hipStream_t st);
 int launch_heads(int S, const float* act, const HeadWeights& hw, int is_ac, float* pi, float* val, int nboards,

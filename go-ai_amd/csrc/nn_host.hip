@@ -28,7 +28,8 @@ static int dev_alloc(goai_ctx* c, void** p, size_t bytes)
 }
 
 constexpr size_t WT_BF16_PER_CONV = (size_t)2 * 9 * 128 * 128;   // hi and lo halves
-constexpr size_t WT_SPLIT6_PER_CONV = (size_t)100 * 8 * 3 * 64 * 8;   // bf16x6: three parts of U = G g Gt, lanes' order
+constexpr size_t WT_SPLIT6_PER_CONV = (size_t)100 * 8 * 3 * 64 * 8;   // bf16x6, F(3x3,3x3): three parts of U = G g Gt, lanes' order
+constexpr size_t WT_SPLIT6_F2_PER_CONV = (size_t)64 * 8 * 3 * 64 * 8;  // bf16x6, F(2x2,3x3)
 
 // float -> bfloat16 bits, round to nearest even (what v_cvt_pk_bf16_f32 does on the device)
 static uint16_t bf16_rne(float f)
@@ -76,8 +77,8 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
                 n.n_cu = prop.multiProcessorCount;
         }
         if (dtype == GOAI_DTYPE_BF16X6) {
-            GOAI_REQUIRE(wino3_supported(c->S), "GOAI_DTYPE_BF16X6 is implemented for 9x9 boards (F(3x3,3x3) tiles the board exactly)");
-            n.wino_mode = 3;
+            // F(3x3,3x3) where it tiles the board exactly (9x9), F(2x2,3x3) elsewhere
+            n.wino_mode = wino3_supported(c->S) ? 3 : 2;
             n.split6 = true;
         }
         if (dtype == GOAI_DTYPE_F32) {
@@ -97,21 +98,22 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
                 }
             }
         }
-        if (n.wino_mode == 2 && (rc = dev_alloc(c, (void**)&n.wt_wino, (size_t)2 * layers * 16 * 128 * 128 * sizeof(float))))
+        if (n.wino_mode == 2 && !n.split6 && (rc = dev_alloc(c, (void**)&n.wt_wino, (size_t)2 * layers * 16 * 128 * 128 * sizeof(float))))
             return rc;
         n.trunk_fused = n.wino_mode == 3 && !getenv("GOAI_NO_TRUNK_FUSION");
         {
             const char* e = getenv("GOAI_WINO3_PAIRED");
             n.wino3_paired = n.wino_mode == 3 && !n.split6 && wino3p_supported(c->S, max_batch, n.n_cu) && !(e && e[0] == '0');
         }
-        if (n.wino3_paired || n.split6) {
+        if (n.wino3_paired || (n.split6 && n.wino_mode == 3)) {
             std::vector<uint16_t> tab(wino3p_build_table(c->S, nullptr));
             wino3p_build_table(c->S, tab.data());
             if ((rc = dev_alloc(c, &n.wino3p_tab, tab.size() * sizeof(uint16_t)))) return rc;
             GOAI_HIP_CHECK(hipMemcpy(n.wino3p_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         }
         if (n.split6) {
-            if ((rc = dev_alloc(c, &n.wt_split6, (size_t)2 * layers * WT_SPLIT6_PER_CONV * sizeof(uint16_t)))) return rc;
+            const size_t per_conv = n.wino_mode == 3 ? WT_SPLIT6_PER_CONV : WT_SPLIT6_F2_PER_CONV;
+            if ((rc = dev_alloc(c, &n.wt_split6, (size_t)2 * layers * per_conv * sizeof(uint16_t)))) return rc;
         } else if (n.wino_mode == 3) {
             if ((rc = dev_alloc(c, (void**)&n.wt_wino3, (size_t)2 * layers * 25 * 128 * 128 * sizeof(float)))) return rc;
             for (int i = 0; i < 2; i++) {
@@ -240,6 +242,38 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
                         }
             GOAI_HIP_CHECK(hipMemcpy((uint16_t*)net.wt_bf16 + (size_t)l * WT_BF16_PER_CONV, wb.data(),
                                      wb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            continue;
+        }
+        if (net.split6 && net.wino_mode == 2) {
+            // bf16x6 on F(2x2,3x3): U = G g Gt (4x4), G = (1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1), folded and rounded to fp32
+            // as for the fp32 kernel, then cut into three bf16 parts; [stage = (chunk * 4 + p) * 4 + q][wave][part][lane][j]
+            static const double Gm[4][3] = { { 1, 0, 0 }, { 0.5, 0.5, 0.5 }, { 0.5, -0.5, 0.5 }, { 0, 0, 1 } };
+            std::vector<uint16_t> ws(WT_SPLIT6_F2_PER_CONV);
+            for (int co = 0; co < 128; co++)
+                for (int ci = 0; ci < 128; ci++) {
+                    const float* g = &w[((size_t)co * 128 + ci) * 9];
+                    for (int pp = 0; pp < 4; pp++)
+                        for (int qq = 0; qq < 4; qq++) {
+                            double u = 0.0;
+                            for (int ky = 0; ky < 3; ky++)
+                                for (int kx = 0; kx < 3; kx++) u += Gm[pp][ky] * Gm[qq][kx] * (double)g[ky * 3 + kx];
+                            float r = (float)(u * sc[co]);
+                            const int chunk = ci / 32, k = ci % 32;
+                            const size_t stage = (size_t)(chunk * 4 + pp) * 4 + qq;
+                            const size_t lane = (size_t)(k / 8) * 16 + co % 16;
+                            for (int part = 0; part < 3; part++) {
+                                uint32_t bits;
+                                memcpy(&bits, &r, 4);
+                                bits &= 0xffff0000u;
+                                float hf;
+                                memcpy(&hf, &bits, 4);
+                                ws[(((stage * 8 + co / 16) * 3 + part) * 64 + lane) * 8 + k % 8] = (uint16_t)(bits >> 16);
+                                r -= hf;                      // exact
+                            }
+                        }
+                }
+            GOAI_HIP_CHECK(hipMemcpy((uint16_t*)net.wt_split6 + (size_t)l * WT_SPLIT6_F2_PER_CONV, ws.data(),
+                                     ws.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             continue;
         }
         if (net.split6) {
@@ -380,6 +414,9 @@ static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const f
         return launch_conv3x3_bf16(c->S, in, (const uint16_t*)net.wt_bf16 + (size_t)l * WT_BF16_PER_CONV, b, resid, out, M,
                                    c->stream);
     const bool wino = net.wino_mode == 2;
+    if (net.split6 && net.wino_mode == 2)
+        return launch_conv3x3_wino2s(c->S, in, (const uint16_t*)net.wt_split6 + (size_t)l * WT_SPLIT6_F2_PER_CONV, b, resid, out,
+                                     M / c->P, c->stream);
     if (net.split6)
         return launch_conv3x3_wino3s(c->S, const_cast<float*>(in), out, resid,
                                      (const uint16_t*)net.wt_split6 + (size_t)l * WT_SPLIT6_PER_CONV, b, net.wino3p_tab, M / c->P, 1,

@@ -122,7 +122,7 @@ class Context:
         self.net_kind = int(net_kind)
         _hip.check(_hip.lib.goai_nn_init(self._h, self.net_kind, int(n_blocks), int(max_batch), int(dtype)))
 
-    CONV_DIRECT, CONV_WINOGRAD, CONV_BF16X3, CONV_WINOGRAD_F3, CONV_WINOGRAD_F3_PAIRED, CONV_WINOGRAD_F3_BF16X6 = 0, 1, 2, 3, 4, 5
+    CONV_DIRECT, CONV_WINOGRAD, CONV_BF16X3, CONV_WINOGRAD_F3, CONV_WINOGRAD_F3_PAIRED, CONV_WINOGRAD_F3_BF16X6, CONV_WINOGRAD_BF16X6 = 0, 1, 2, 3, 4, 5, 6
 
     def nn_conv_algo(self):
         """The 3x3 convolution kernel nn_init chose for this context (CONV_*)."""

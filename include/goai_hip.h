@@ -97,7 +97,7 @@ int goai_liberties(goai_ctx* ctx, const uint8_t* states, int32_t* black_libs, in
                              * transform-domain products run as SIX bf16 MFMAs on operands split exactly into three bf16
                              * parts each (24 significant bits; the dropped cross terms are below 2^-24 of a product),
                              * fp32 accumulate, fp32 transforms.  Outputs agree with the exact-fp32 kernels at their own
-                             * rounding level (tests/test_gpu_nn.py).  9x9 boards. */
+                             * rounding level (tests/test_gpu_nn.py).  F(3x3,3x3) on 9x9 boards, F(2x2,3x3) on the others. */
 #define GOAI_NN_RAW 0       /* the nn.Module outputs (ac_net.forward / val_net.forward) */
 #define GOAI_NN_NUMPY_SHIM 1 /* + RLNet._numpy post-processing, models/__init__.py:90-105 */
 
@@ -118,7 +118,8 @@ int goai_nn_init(goai_ctx* ctx, int net_kind, int n_blocks, int max_batch, int d
 #define GOAI_CONV_BF16X3 2
 #define GOAI_CONV_WINOGRAD_F3 3 /* Winograd F(3x3,3x3), fp32: 9x9 boards */
 #define GOAI_CONV_WINOGRAD_F3_PAIRED 4 /* the same with two 32-channel chunks per output transform: 9x9, max_batch <= 4 boards per CU */
-#define GOAI_CONV_WINOGRAD_F3_BF16X6 5 /* GOAI_DTYPE_BF16X6 contexts */
+#define GOAI_CONV_WINOGRAD_F3_BF16X6 5 /* GOAI_DTYPE_BF16X6 contexts, 9x9: F(3x3,3x3) */
+#define GOAI_CONV_WINOGRAD_BF16X6 6    /* GOAI_DTYPE_BF16X6 contexts, other boards: F(2x2,3x3) */
 int goai_nn_conv_algo(goai_ctx* ctx);
 
 /* How many of the trunk's 3x3 convolutions one kernel launch of this context runs (no reference
