@@ -290,3 +290,59 @@ def test_c4_sampled_games_match_sequential_oracle(full_c4):
         assert np.array_equal(counts.astype(np.int32), visits[g]), f"game {g}"
         assert np.array_equal(opi, pi[g])
     c.close()
+
+
+# =================================================================================================
+# The arithmetic bench.py runs by default since round 2: GOAI_DTYPE_BF16X6 (Winograd products on the bf16 matrix
+# cores, three-way split operands).  Same properties at C2's and C4's full sizes, and sampled games replayed by
+# the sequential oracle fed the bf16x6 network's own logits: the search is bit-exact whatever produced the logits.
+# =================================================================================================
+def _search_x6(size, games, sims, roots, offset=0, max_batch=None):
+    from go_ai.engine import Context
+    from go_ai.models import random_state_dict
+    c = Context(size)
+    c.nn_init(Context.NET_AC, 3, max_batch or games, dtype=Context.DTYPE_BF16X6)
+    c.load_weights(random_state_dict("ac", size, 0, 3))
+    c.mcts_init(games, sims)
+    c.mcts_reset(roots)
+    c.mcts_run(sims)
+    visits, prior, root_visits = [t.cpu().numpy() for t in c.mcts_readout()]
+    pi = c.mcts_policy(1.0)
+    acts = c.sample_actions(pi, 1234, 0, offset).cpu().numpy()
+    cnt = c.mcts_counters()
+    return c, visits, prior, root_visits, pi.cpu().numpy(), acts, cnt
+
+
+@pytest.mark.parametrize("size,games,sims,random_moves,step", [(9, 1024, 81, 40, 128), (13, 8192, 81, 80, 2048)])
+def test_bf16x6_full_config_search(size, games, sims, random_moves, step):
+    from go_ai.engine import Context
+    roots = _roots_of(size, games, sims, random_moves, "ac")
+    c, visits, prior, root_visits, pi, acts, cnt = _search_x6(size, games, sims, roots)
+    assert c.nn_conv_algo() == (Context.CONV_WINOGRAD_F3_BF16X6 if size == 9 else Context.CONV_WINOGRAD_BF16X6)
+    assert cnt["errors"] == 0 and cnt["leaf_evals"] == games * (sims + 1)
+    st = roots.cpu().numpy()
+    valid = _valid_of(st)
+    assert (root_visits == sims + 1).all() and (visits.sum(axis=1) == sims).all() and (visits >= 0).all()
+    assert (visits[~valid] == 0).all() and (prior[~valid] == 0).all() and (pi[~valid] == 0).all()
+    assert np.allclose(prior.sum(axis=1), 1, atol=1e-6) and np.allclose(pi.sum(axis=1), 1, atol=1e-12)
+    want = 0.98 * (visits / visits.sum(axis=1, keepdims=True)) + 0.02 * valid / valid.sum(axis=1, keepdims=True)
+    assert np.allclose(pi, want, rtol=1e-12, atol=1e-15)
+    assert valid[np.arange(games), acts].all()
+
+    def net(states):
+        p, v = c.nn_forward(np.asarray(states).astype(np.uint8), mode=c.NN_NUMPY_SHIM)
+        return p.cpu().numpy(), v.cpu().numpy()
+
+    for g in range(3, games, step):            # a sample of the games, replayed sequentially on the oracle
+        env = GoEnv(size)
+        env.state = st[g].astype(np.float64)
+        opi, counts, _ = mcts_ref.actor_critic_policy(env, net, sims, 1.0, math="det")
+        assert np.array_equal(counts.astype(np.int32), visits[g]), f"game {g}"
+        assert np.array_equal(opi, pi[g])
+    c.close()
+    # two shards of half the games (what two GPUs would own): bit-identical searches and draws
+    half = games // 2
+    for lo in (0, half):
+        c2, v, p, _, q, a, _ = _search_x6(size, half, sims, roots[lo:lo + half], offset=lo, max_batch=games)
+        c2.close()
+        assert np.array_equal(v, visits[lo:lo + half]) and np.array_equal(q, pi[lo:lo + half]) and np.array_equal(a, acts[lo:lo + half])
