@@ -63,6 +63,7 @@ int wino3p_supported(int S, int max_batch, int n_cu);
 size_t wino3p_build_table(int S, uint16_t* out);
 int launch_conv3x3_wino3p(int S, float* x, float* y, const float* resid0, const float* wt_wino3, const float* bias,
                           const void* tab, int nboards, int n_cu, int n_convs, hipStream_t st);
+size_t wino3s_build_table(int S, uint16_t* out);
 int launch_conv3x3_wino3s(int S, float* x, float* y, const float* resid0, const void* wt_split, const float* bias,
                           const void* tab, int nboards, int n_convs, hipStream_t st);
 int launch_conv3x3_wino2s(int S, const float* in, const void* wt_split, const float* bias, const float* resid, float* out,

@@ -107,7 +107,8 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
         }
         if (n.wino3_paired || (n.split6 && n.wino_mode == 3)) {
             std::vector<uint16_t> tab(wino3p_build_table(c->S, nullptr));
-            wino3p_build_table(c->S, tab.data());
+            if (n.split6) wino3s_build_table(c->S, tab.data());
+            else wino3p_build_table(c->S, tab.data());
             if ((rc = dev_alloc(c, &n.wino3p_tab, tab.size() * sizeof(uint16_t)))) return rc;
             GOAI_HIP_CHECK(hipMemcpy(n.wino3p_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         }
