@@ -347,8 +347,86 @@ def gen_temps():
     gen_mcts_q("fake_flat5_n30_t0", 5, 30, roots5[:3], lambda i: fake_critic("flat", np.random.default_rng(300 + i)), temp=0.0)
 
 
+def train_batch(size, B, seed):
+    """A synthetic replay batch in the layout train_step receives (data.py:92-105): states, actions, children,
+    wins, pi -- positions from seeded random play, one valid action each, a random target policy over the valid moves."""
+    rng = np.random.default_rng(seed)
+    states = random_positions(size, B, seed, canonical=True, pass_prob=0.05).astype(np.float64)
+    A = size * size + 1
+    children = np.stack([np.asarray(og.GoGame.children(st, canonical=True, padded=True)) for st in states])
+    valid = np.stack([og.GoGame.valid_moves(st) for st in states])
+    actions = np.array([int(rng.choice(np.flatnonzero(v))) for v in valid])
+    wins = rng.choice([-1, 0, 1], size=B, p=[0.45, 0.1, 0.45])
+    pi = rng.random((B, A)) ** 4 * valid
+    pi = pi / pi.sum(axis=1, keepdims=True)
+    return states, actions, children, wins, pi
+
+
+def gen_train(kind, size, seed, B, steps=2):
+    """The reference's own train_step (ac_net.py:67-86 / val_net.py:29-43) with torch.optim.Adam(lr=1e-3,
+    weight_decay=1e-4) (train.py:52) on its real nn.Module, `steps` consecutive batches.  One shim, so that the
+    inputs of the step are data and not a draw of numpy's global generator: data.batch_random_symmetries is the
+    identity here (the HIP entry point receives next_states after that augmentation anyway).
+    Stored: the batches, the metrics, and after every step 24 sampled entries + the L2 norm of every parameter,
+    of the gradient the optimiser consumed, and every BatchNorm running statistic in full."""
+    net, sd0 = ref_net(kind, size, seed)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-4)
+    saved_sym = ref_data.batch_random_symmetries
+    ref_data.batch_random_symmetries = lambda states: np.asarray(states)
+    names = {id(p): n for n, p in net.named_parameters()}
+    keys = [k for k in sd0 if not k.endswith(("running_mean", "running_var"))]
+    stat_keys = [k for k in sd0 if k.endswith(("running_mean", "running_var"))]
+    rng = np.random.default_rng(4242)
+    sample_idx = {k: rng.integers(0, sd0[k].numel(), 24) for k in keys}
+    out = dict(kind=kind, size=size, seed=seed, steps=steps, digest=nn_ref.state_dict_digest(sd0))
+    for k in keys:
+        out["idx_" + k] = sample_idx[k]
+    try:
+        for s in range(steps):
+            states, actions, children, wins, pi = train_batch(size, B, 9000 + 10 * seed + s)
+            grads = {}
+            orig_step = opt.step
+
+            def recording_step(*a, **kw):
+                for group in opt.param_groups:
+                    for p in group["params"]:
+                        if p.grad is not None:
+                            grads[names[id(p)]] = p.grad.detach().clone()
+                return orig_step(*a, **kw)
+
+            opt.step = recording_step
+            metrics = net.train_step(opt, states, actions, None, children, None, wins, pi)
+            opt.step = orig_step
+            out[f"s{s}_states"] = states.astype(np.uint8)
+            out[f"s{s}_next_states"] = children[np.arange(B), actions].astype(np.uint8)
+            out[f"s{s}_wins"] = wins.astype(np.int64)
+            out[f"s{s}_pi"] = pi.astype(np.float32)
+            out[f"s{s}_metrics"] = np.array([np.nan if m is None else m for m in metrics], dtype=np.float64)
+            now = net.state_dict()
+            for k in keys:
+                assert k in grads, k
+                g = grads[k].numpy().reshape(-1)
+                w = now[k].detach().numpy().reshape(-1)
+                out[f"s{s}_grad_{k}"] = np.concatenate([g[sample_idx[k]], [np.linalg.norm(g.astype(np.float64))]])
+                out[f"s{s}_param_{k}"] = np.concatenate([w[sample_idx[k]], [np.linalg.norm(w.astype(np.float64))]])
+            for k in stat_keys:
+                out[f"s{s}_stat_{k}"] = now[k].detach().numpy().copy()
+            assert not any(k.startswith("game_head") for k in grads), "game_head takes no part in train_step"
+    finally:
+        ref_data.batch_random_symmetries = saved_sym
+    path = os.path.join(HERE, f"train_{kind}{size}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "metrics", [out[f"s{s}_metrics"] for s in range(steps)])
+
+
 def main():
     torch.manual_seed(0)
+    if "--only-train" in sys.argv:       # add the training fixtures without rewriting the others
+        gen_train("ac", 5, 31, 16)
+        gen_train("ac", 9, 32, 32)
+        gen_train("val", 9, 33, 32)
+        return
     if "--only-temps" in sys.argv:       # add the temperature / helper fixtures without rewriting the others
         gen_search_helpers()
         gen_temps()
@@ -399,6 +477,9 @@ def main():
     gen_mcts_q("fake_wide9_n20", 9, 20, roots9[:2], lambda i: fake_critic("wide", np.random.default_rng(400 + i)))
     gen_search_helpers()
     gen_temps()
+    gen_train("ac", 5, 31, 16)
+    gen_train("ac", 9, 32, 32)
+    gen_train("val", 9, 33, 32)
 
 
 if __name__ == "__main__":
