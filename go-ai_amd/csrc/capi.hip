@@ -21,7 +21,7 @@ using namespace goai;
 extern "C" {
 
 const char* goai_last_error(void) { return g_last_error.c_str(); }
-int goai_version(void) { return 3; }
+int goai_version(void) { return 4; }
 
 int goai_ctx_create(goai_ctx** out, int device, int board_size)
 {
@@ -364,6 +364,55 @@ int goai_mcts_counters(goai_ctx* ctx, int64_t* counters_host)
         counters_host[k] = sum;
     }
     return GOAI_OK;
+}
+
+int goai_train_init(goai_ctx* ctx, int net_kind, int n_blocks, int max_batch)
+{
+    CTX_ENTER(ctx);
+    return train_init(ctx, net_kind, n_blocks, max_batch);
+}
+
+int goai_train_load(goai_ctx* ctx, const char* const* names, const float* const* tensors_host, const int64_t* numels,
+                    int n_tensors, int strict)
+{
+    CTX_ENTER(ctx);
+    return train_load(ctx, names, tensors_host, numels, n_tensors, strict);
+}
+
+int goai_train_export(goai_ctx* ctx, int what, const char* const* names, float* const* tensors_host, const int64_t* numels,
+                      int n_tensors)
+{
+    CTX_ENTER(ctx);
+    return train_export(ctx, what, names, tensors_host, numels, n_tensors);
+}
+
+int goai_train_reset_optimizer(goai_ctx* ctx)
+{
+    CTX_ENTER(ctx);
+    return train_reset_optimizer(ctx);
+}
+
+int goai_train_step(goai_ctx* ctx, const uint8_t* states, const uint8_t* next_states, const float* wins, const float* pi,
+                    int n, float lr, float weight_decay, float* metrics_host)
+{
+    CTX_ENTER(ctx);
+    return train_step(ctx, states, next_states, wins, pi, n, lr, weight_decay, metrics_host);
+}
+
+int goai_train_params(goai_ctx* ctx, float** params_device, int64_t* numel)
+{
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(ctx->train.ready, "call goai_train_init first");
+    GOAI_REQUIRE(params_device && numel, "NULL output");
+    *params_device = ctx->train.params;
+    *numel = (int64_t)ctx->train.n_params;
+    return GOAI_OK;
+}
+
+int goai_train_sync_inference(goai_ctx* ctx)
+{
+    CTX_ENTER(ctx);
+    return train_sync_inference(ctx);
 }
 
 int goai_profile_enable(goai_ctx* ctx, int enable)

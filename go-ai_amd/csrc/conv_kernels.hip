@@ -56,7 +56,7 @@ struct ConvCfg {
 template <int S, int RT, bool RESID>
 __global__ __launch_bounds__(256, 3) void k_conv3x3(const float* __restrict__ in, const float* __restrict__ wt,
                                                     const float* __restrict__ bias, const float* __restrict__ resid,
-                                                    float* __restrict__ out, int M)
+                                                    float* __restrict__ out, int M, float floor_v)
 {
     using G = Geom<S>;
     using C = ConvCfg<S, RT>;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3(const float* __restrict__ in
                 for (int r = 0; r < 4; r++) {
                     float v = acc[t][tn][r] + bv;
                     if (RESID) v += rv[t][r];
-                    out[((long)m0 + t * 16 + 4 * lq + r) * 128 + col] = fmaxf(v, 0.0f);
+                    out[((long)m0 + t * 16 + 4 * lq + r) * 128 + col] = fmaxf(v, floor_v);
                 }
         } else {
 #pragma unroll
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3(const float* __restrict__ in
                     if (row < M) {
                         float v = acc[t][tn][r] + bv;
                         if (RESID) v += resid[row * 128 + col];
-                        out[row * 128 + col] = fmaxf(v, 0.0f);
+                        out[row * 128 + col] = fmaxf(v, floor_v);
                     }
                 }
         }
@@ -310,22 +310,22 @@ static int pick_rt(int S, int M)
 
 template <int S, int RT>
 static void launch_rt(const float* in, const float* wt, const float* bias, const float* resid, float* out, int M,
-                      hipStream_t st)
+                      float floor_v, hipStream_t st)
 {
     const int grid = (M + 16 * RT - 1) / (16 * RT);
-    if (resid) k_conv3x3<S, RT, true><<<dim3(grid), dim3(256), 0, st>>>(in, wt, bias, resid, out, M);
-    else k_conv3x3<S, RT, false><<<dim3(grid), dim3(256), 0, st>>>(in, wt, bias, resid, out, M);
+    if (resid) k_conv3x3<S, RT, true><<<dim3(grid), dim3(256), 0, st>>>(in, wt, bias, resid, out, M, floor_v);
+    else k_conv3x3<S, RT, false><<<dim3(grid), dim3(256), 0, st>>>(in, wt, bias, resid, out, M, floor_v);
 }
 
 template <int S>
 static void launch_s(int rt, const float* in, const float* wt, const float* bias, const float* resid, float* out, int M,
-                     hipStream_t st)
+                     float floor_v, hipStream_t st)
 {
     switch (rt) {
-        case 5: launch_rt<S, 5>(in, wt, bias, resid, out, M, st); break;
-        case 6: launch_rt<S, 6>(in, wt, bias, resid, out, M, st); break;
-        case 7: launch_rt<S, 7>(in, wt, bias, resid, out, M, st); break;
-        default: launch_rt<S, 8>(in, wt, bias, resid, out, M, st); break;
+        case 5: launch_rt<S, 5>(in, wt, bias, resid, out, M, floor_v, st); break;
+        case 6: launch_rt<S, 6>(in, wt, bias, resid, out, M, floor_v, st); break;
+        case 7: launch_rt<S, 7>(in, wt, bias, resid, out, M, floor_v, st); break;
+        default: launch_rt<S, 8>(in, wt, bias, resid, out, M, floor_v, st); break;
     }
 }
 
@@ -336,14 +336,28 @@ extern "C" int goai_debug_conv_stamps(unsigned long long* host_out, int n)
 }
 #endif
 
-int launch_conv3x3(int S_rt, const float* in, const float* wt, const float* bias, const float* resid, float* out,
-                   int M, hipStream_t st)
+static int launch_conv3x3_floor(int S_rt, const float* in, const float* wt, const float* bias, const float* resid, float* out,
+                                int M, float floor_v, hipStream_t st)
 {
     static const int forced = [] { const char* e = getenv("GOAI_CONV_RT"); return e ? atoi(e) : 0; }();   // tuning aid
     const int rt = (forced >= 5 && forced <= 8) ? forced : pick_rt(S_rt, M);
-    GOAI_DISPATCH_SIZE(S_rt, launch_s<S>(rt, in, wt, bias, resid, out, M, st));
+    GOAI_DISPATCH_SIZE(S_rt, launch_s<S>(rt, in, wt, bias, resid, out, M, floor_v, st));
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
+}
+
+int launch_conv3x3(int S_rt, const float* in, const float* wt, const float* bias, const float* resid, float* out,
+                   int M, hipStream_t st)
+{
+    return launch_conv3x3_floor(S_rt, in, wt, bias, resid, out, M, 0.0f, st);
+}
+
+// The same implicit GEMM without the ReLU: out = conv(in) + bias (+ resid).  The training path uses it for the
+// convolutions in front of a train-mode BatchNorm and, with transposed / flipped weights, for the data gradient.
+int launch_conv3x3_linear(int S_rt, const float* in, const float* wt, const float* bias, const float* resid, float* out,
+                          int M, hipStream_t st)
+{
+    return launch_conv3x3_floor(S_rt, in, wt, bias, resid, out, M, -INFINITY, st);
 }
 
 }  // namespace goai

@@ -7,6 +7,7 @@
 
 #include "mcts.h"
 #include "nn.h"
+#include "train.h"
 
 struct goai_ctx {
     int device = 0;
@@ -19,6 +20,7 @@ struct goai_ctx {
     bool prof_enabled = false;
     std::vector<hipEvent_t> prof_events;   // start/stop pairs
     goai::Tree tree;
+    goai::Train train;
 
     void release()
     {

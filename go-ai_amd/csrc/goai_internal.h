@@ -54,6 +54,15 @@ int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, in
 int nn_static_setup(int device);   // once per device, with that device current (goai_ctx_create)
 int nn_forward_static(goai_ctx* c, const uint8_t* states, float* pi, float* val, int n);
 
+// ---- optimisation step (train_host.hip) ----
+int train_init(goai_ctx* c, int kind, int layers, int max_batch);
+int train_load(goai_ctx* c, const char* const* names, const float* const* tensors, const int64_t* numels, int n, int strict);
+int train_reset_optimizer(goai_ctx* c);
+int train_export(goai_ctx* c, int what, const char* const* names, float* const* tensors, const int64_t* numels, int n);
+int train_step(goai_ctx* c, const uint8_t* states, const uint8_t* next_states, const float* wins, const float* pi, int n, float lr,
+               float weight_decay, float* metrics_host);
+int train_sync_inference(goai_ctx* c);
+
 // ---- search (mcts_host.hip) ----
 int mcts_init(goai_ctx* c, int n_games, int max_sims, int mode);
 int mcts_reset(goai_ctx* c, const uint8_t* roots);

@@ -49,6 +49,8 @@ int launch_conv0(int S, const uint8_t* states, const float* w0, const void* w0_s
                  float* out, int nboards, hipStream_t st);
 int launch_conv3x3(int S, const float* in, const float* wt, const float* bias, const float* resid, float* out, int M,
                    hipStream_t st);
+int launch_conv3x3_linear(int S, const float* in, const float* wt, const float* bias, const float* resid, float* out, int M,
+                          hipStream_t st);
 int launch_conv3x3_bf16(int S, const float* in, const void* wt_bf16, const float* bias, const float* resid, float* out,
                         int M, hipStream_t st);
 int wino_boards_per_wg(int S);

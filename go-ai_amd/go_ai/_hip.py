@@ -65,6 +65,14 @@ _SIGNATURES = {
     "goai_mcts_game_stats": [c_void_p, ctypes.POINTER(c_int64)],
     "goai_mcts_roots": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "goai_mcts_counters": [c_void_p, ctypes.POINTER(c_int64)],
+    "goai_train_init": [c_void_p, c_int, c_int, c_int],
+    "goai_train_load": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int],
+    "goai_train_export": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int],
+    "goai_train_reset_optimizer": [c_void_p],
+    "goai_train_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_float, ctypes.c_float,
+                        ctypes.POINTER(ctypes.c_float)],
+    "goai_train_params": [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64)],
+    "goai_train_sync_inference": [c_void_p],
     "goai_profile_enable": [c_void_p, c_int],
     "goai_profile_read": [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64)],
 }

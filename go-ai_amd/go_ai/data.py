@@ -112,6 +112,10 @@ class SoloComm:
     def Barrier(self):
         pass
 
+    def allreduce(self, x):
+        """comm.allreduce(x, op=MPI.SUM) of one process: x itself."""
+        return x
+
 
 class TorchComm:
     """The communicator calls the replay code needs, over the default torch.distributed group
@@ -129,6 +133,29 @@ class TorchComm:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
             dist.barrier()
+
+    def allreduce(self, x):
+        """comm.allreduce(x, op=MPI.SUM) (models/__init__.py:226,282).  A torch tensor is summed IN PLACE over the
+        ranks and returned (a GPU tensor goes over RCCL when the group's backend is nccl, through the host
+        otherwise); numbers and numpy arrays come back as new float64 arrays."""
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return x
+        if torch.is_tensor(x):
+            if x.is_cuda and dist.get_backend() != "nccl":
+                host = x.detach().cpu()
+                dist.all_reduce(host)
+                x.copy_(host)
+            else:
+                dist.all_reduce(x)
+            return x
+        t = torch.as_tensor(np.asarray(x, dtype=np.float64))
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t)
+        out = t.cpu().numpy()
+        return out if np.ndim(x) else float(out)
 
 
 def load_replay(replay_path):

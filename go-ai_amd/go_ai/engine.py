@@ -154,6 +154,79 @@ class Context:
         c_numels = (ctypes.c_int64 * n)(*[a.size for a in arrays])
         _hip.check(_hip.lib.goai_load_weights(self._h, c_names, c_ptrs, c_numels, n))
 
+    # ---- optimisation step (include/goai_hip.h: goai_train_*) ---------------------------
+    @staticmethod
+    def _tensor_table(items):
+        names = [k.encode() for k, _ in items]
+        n = len(names)
+        return (n, (ctypes.c_char_p * n)(*names), (ctypes.c_void_p * n)(*[a.ctypes.data for _, a in items]),
+                (ctypes.c_int64 * n)(*[a.size for _, a in items]))
+
+    def train_init(self, net_kind, n_blocks=3, max_batch=32):
+        self._bind()
+        self.train_kind = int(net_kind)
+        _hip.check(_hip.lib.goai_train_init(self._h, self.train_kind, int(n_blocks), int(max_batch)))
+
+    def train_load(self, state_dict, strict=True):
+        """Parameters and BatchNorm statistics from a state_dict in the reference's key layout (host tensors / arrays)."""
+        self._bind()
+        items = []
+        for k, v in state_dict.items():
+            a = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+            if a.dtype.kind == "f":             # not num_batches_tracked
+                items.append((k, np.ascontiguousarray(a, dtype=np.float32)))
+        n, names, ptrs, numels = self._tensor_table(items)
+        _hip.check(_hip.lib.goai_train_load(self._h, names, ptrs, numels, n, int(bool(strict))))
+
+    TRAIN_VALUES, TRAIN_GRADS, TRAIN_ADAM_M, TRAIN_ADAM_V = 0, 1, 2, 3
+
+    def train_export(self, shapes, what=0):
+        """shapes: mapping key -> shape; returns key -> float32 numpy array of that shape (`what`: TRAIN_*)."""
+        self._bind()
+        items = [(k, np.empty(tuple(shape), dtype=np.float32)) for k, shape in shapes.items()]
+        n, names, ptrs, numels = self._tensor_table(items)
+        _hip.check(_hip.lib.goai_train_export(self._h, int(what), names, ptrs, numels, n))
+        return dict(items)
+
+    def train_reset_optimizer(self):
+        self._bind()
+        _hip.check(_hip.lib.goai_train_reset_optimizer(self._h))
+
+    def train_step(self, states, next_states, wins, pi, lr=1e-3, weight_decay=1e-4):
+        """goai_train_step; returns (critic_loss, critic_acc, actor_loss, actor_acc), the last two None for the value net."""
+        self._bind()
+        nxt = _dev_u8_states(next_states, self.device)
+        n = nxt.shape[0]
+        w = torch.as_tensor(np.asarray(wins, dtype=np.float32) if not torch.is_tensor(wins) else wins)
+        w = w.to(self.device, dtype=torch.float32).contiguous()
+        st = p = None
+        if self.train_kind == self.NET_AC:
+            st = _dev_u8_states(states, self.device)
+            p = torch.as_tensor(np.asarray(pi, dtype=np.float32) if not torch.is_tensor(pi) else pi)
+            p = p.to(self.device, dtype=torch.float32).contiguous()
+            assert st.shape[0] == n and tuple(p.shape) == (n, self.A), (st.shape, p.shape)
+        assert w.numel() == n
+        m = (ctypes.c_float * 4)()
+        _hip.check(_hip.lib.goai_train_step(self._h, _hip.ptr(st), _hip.ptr(nxt), _hip.ptr(w), _hip.ptr(p), n,
+                                            float(lr), float(weight_decay), m))
+        vals = [float(x) for x in m]
+        return tuple(None if np.isnan(v) else v for v in vals)
+
+    def train_params(self):
+        """The flat fp32 parameter buffer as a torch DEVICE tensor (a view, not a copy): all-reduce it in place to
+        average the model over ranks."""
+        self._bind()
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        _hip.check(_hip.lib.goai_train_params(self._h, ctypes.byref(p), ctypes.byref(n)))
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (n.value,), "typestr": "<f4", "data": (p.value, False), "version": 2}
+        return torch.as_tensor(_View(), device=self.device)
+
+    def train_sync_inference(self):
+        self._bind()
+        _hip.check(_hip.lib.goai_train_sync_inference(self._h))
+
     def nn_forward(self, states, mode=0, want_pi=True):
         self._bind()
         st = _dev_u8_states(states, self.device)

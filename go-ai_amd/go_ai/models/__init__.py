@@ -14,6 +14,55 @@ CHANNELS = 128
 LAYERS = 3
 
 
+class Adam:
+    """What the reference's callers build with torch.optim.Adam(model.parameters(), args.lr, weight_decay=1e-4)
+    (/root/reference/train.py:52) and hand to optimize(): here only the two numbers -- the moments and the step
+    count live on the GPU next to the parameters (goai_train_step)."""
+
+    def __init__(self, params=None, lr=1e-3, weight_decay=1e-4):
+        self.lr, self.weight_decay = float(lr), float(weight_decay)
+
+    def zero_grad(self):
+        pass
+
+
+class ModelMetrics:
+    """Losses and accuracies of one optimize() call (/root/reference/go_ai/models/__init__.py:254-276)."""
+
+    def __init__(self, cl=None, ca=None, al=None, aa=None, gl=None):
+        self.crit_loss, self.crit_acc = cl, ca
+        self.act_loss, self.act_acc = al, aa
+        self.game_loss = gl
+
+    @staticmethod
+    def _has(x):
+        return x is not None and not np.isnan(x)
+
+    def __str__(self):
+        ret = ''
+        if self._has(self.crit_loss):
+            ret += f'C[{self.crit_acc * 100 :.1f}% {self.crit_loss:.3f}L] '
+        if self._has(self.act_loss):
+            ret += f'A[{self.act_acc * 100 :.1f}% {self.act_loss:.3f}L] '
+        if self._has(self.game_loss):
+            ret += f'G[{self.game_loss:.3f}L] '
+        return ret
+
+    __repr__ = __str__
+
+
+def average_model(comm, model):
+    """Every rank ends up with the mean of the ranks' parameters; BatchNorm statistics are not touched
+    (/root/reference/go_ai/models/__init__.py:279-282).  One all-reduce of the flat parameter buffer (RCCL on the
+    GPU view when the group runs on nccl) instead of the reference's one per tensor."""
+    world_size = comm.Get_size()
+    if world_size == 1:
+        return
+    flat = model.flat_parameters()
+    comm.allreduce(flat)
+    flat.div_(world_size)
+
+
 def random_state_dict(kind, size, seed=0, layers=LAYERS):
     """Random-init weights in the reference's state_dict layout (there are no pretrained
     weights to load: the reference git-ignores *.pt).  BN statistics are randomised too."""
@@ -64,8 +113,11 @@ class RLNet:
     kind = None
     MAX_SEARCH_CONTEXTS = 4      # tree storage is kept for the last few (n_games, max_sims, mode) combinations only
 
-    def __init__(self, size, device=0, n_blocks=LAYERS, max_batch=512):
+    def __init__(self, size, device=0, n_blocks=LAYERS, max_batch=512, train_batch=256):
         from ..engine import Context
+        self.train_batch = train_batch       # largest batch train_step accepts (its buffers are allocated on first use)
+        self._train = None
+        self._train_dirty = False
         self.size = size
         self.layers = n_blocks
         self.channels = CHANNELS
@@ -83,15 +135,83 @@ class RLNet:
     def load_state_dict(self, state_dict, strict=False):
         self._sd = {k: (v.detach().cpu().float().clone() if torch.is_tensor(v) else torch.as_tensor(v).float())
                     for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
+        self._push_inference()
+        if self._train is not None:          # like nn.Module.load_state_dict under a live optimiser: Adam's state stays
+            self._train.train_load(self._sd)
+        self._train_dirty = False
+
+    def _push_inference(self):
         self.ctx.load_weights(self._sd)
         for c in self._search.values():
             c.load_weights(self._sd)
 
     def state_dict(self):
+        self._pull_trained()
         return dict(self._sd)
 
     def eval(self):
+        self._pull_trained()
         return self
+
+    # -- optimisation (models/__init__.py:115-231, ac_net.py:67-86, val_net.py:29-43) -----
+    def train(self):
+        """Training state on the GPU (goai_train_init): raw parameters, gradients, Adam moments, BatchNorm statistics."""
+        if self._train is None:
+            from ..engine import Context
+            self._train = Context(self.size, self.device_index)
+            self._train.train_init(Context.NET_AC if self.kind == "ac" else Context.NET_VAL, self.layers, self.train_batch)
+            self._train.train_load(self._sd)
+        return self
+
+    def _tensor_shapes(self):
+        return {k: tuple(v.shape) for k, v in self._sd.items() if not k.startswith("game_head.")}
+
+    def _pull_trained(self):
+        """Trained parameters and statistics back into the state_dict and the inference / search contexts."""
+        if self._train is not None and self._train_dirty:
+            for k, v in self._train.train_export(self._tensor_shapes()).items():
+                self._sd[k] = torch.from_numpy(v)
+            self._push_inference()
+            self._train_dirty = False
+
+    def flat_parameters(self):
+        """All parameters as one flat GPU tensor (a view of the training buffer): what average_model all-reduces."""
+        self.train()
+        self._train_dirty = True
+        return self._train.train_params()
+
+    def train_step(self, optimizer, states, actions, reward, children, terminal, wins, pi):
+        """One optimisation step on a batch of events (ac_net.py:67-86 / val_net.py:29-43): the critic learns -wins on
+        next_states = children[actions] under random board symmetries, the actor (actor-critic net) argmax(pi) on
+        states.  Returns (critic loss, critic accuracy, actor loss, actor accuracy), None where the net has no actor."""
+        from .. import data
+        self.train()
+        children = np.asarray(children)
+        bsz = len(children)
+        next_states = children[np.arange(bsz), np.asarray(actions)]
+        next_states = data.batch_random_symmetries(next_states)          # train_step's own
+        next_states = data.batch_random_symmetries(next_states)          # critic_step's (models/__init__.py:119)
+        self._train_dirty = True
+        return self._train.train_step(states if self.kind == "ac" else None, next_states, np.asarray(wins, dtype=np.float32),
+                                      pi if self.kind == "ac" else None, lr=optimizer.lr, weight_decay=optimizer.weight_decay)
+
+    def optimize(self, comm, batched_data, optimizer):
+        """RLNet.optimize (models/__init__.py:210-231): train_step over the batches, then parameters and metrics
+        averaged over the ranks."""
+        import warnings
+        from ..data import SoloComm
+        comm = comm if comm is not None else SoloComm()
+        self.train()
+        raw_metrics = [self.train_step(optimizer, *batch) for batch in batched_data]
+        average_model(comm, self)
+        world_size = comm.Get_size()
+        raw_metrics = np.array(raw_metrics, dtype=float).reshape(-1, 4)          # None -> nan
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", category=RuntimeWarning)
+            mean_metrics = np.nanmean(raw_metrics, axis=0) if len(raw_metrics) else np.full(4, np.nan)
+        reduced_metrics = np.asarray(comm.allreduce(mean_metrics)) / world_size
+        self._pull_trained()
+        return ModelMetrics(*reduced_metrics)
 
     def to(self, device):
         return self
@@ -99,6 +219,7 @@ class RLNet:
     def search_context(self, n_games, max_sims, mode=0):
         """A context with tree storage for (n_games, max_sims, search mode), sharing this net's weights."""
         from ..engine import Context
+        self._pull_trained()
         key = (n_games, max_sims, mode)
         if key in self._search:
             self._search[key] = self._search.pop(key)            # most recently used last
@@ -123,6 +244,7 @@ class RLNet:
 
     def _numpy(self, states, mode, children=None):
         """RLNet._numpy (models/__init__.py:54-113): numpy in, numpy float32 logits out."""
+        self._pull_trained()
         states = np.asarray(states)
         assert states.ndim == 4, states.shape
         if mode == "critic":

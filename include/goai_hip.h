@@ -304,6 +304,56 @@ int goai_mcts_roots(goai_ctx* ctx, uint8_t* states, int32_t* turn, int32_t* move
 int goai_mcts_counters(goai_ctx* ctx, int64_t* counters_host);
 
 /* ---------------------------------------------------------------------------------------
+ * Optimisation step: one train_step of the reference's networks
+ *   ActorCriticNet.train_step  /root/reference/go_ai/models/ac_net.py:67-86
+ *   ValueNet.train_step        /root/reference/go_ai/models/val_net.py:29-43
+ *   RLNet.critic_step / actor_step  /root/reference/go_ai/models/__init__.py:115-134,167-186
+ *   torch.optim.Adam(lr, weight_decay)  /root/reference/train.py:52
+ * in fp32 on the GPU: train-mode forward (BatchNorm on the batch's own statistics, running
+ * statistics moved with momentum 0.1), backward, Adam.  A context carries the training copy of
+ * a net (raw parameters, gradients, Adam moments, BatchNorm statistics) next to, and
+ * independent of, the folded inference images of goai_nn_init.
+ * ------------------------------------------------------------------------------------- */
+/* Allocate the training state for batches of up to max_batch positions; parameters start at
+ * zero (goai_train_load fills them). */
+int goai_train_init(goai_ctx* ctx, int net_kind, int n_blocks, int max_batch);
+
+/* Parameters and BatchNorm running statistics from HOST fp32 tensors by state_dict key, the
+ * table format of goai_load_weights (game_head.* and *.num_batches_tracked are skipped).
+ * strict != 0: every tensor of the net must be in the table.  Adam's state is not touched. */
+int goai_train_load(goai_ctx* ctx, const char* const* names, const float* const* tensors_host,
+                    const int64_t* numels, int n_tensors, int strict);
+
+/* Copy named tensors out to HOST buffers: what = 0 the values (parameters, statistics),
+ * 1 the gradients the last step's optimiser consumed (before weight decay), 2 / 3 Adam's
+ * first / second moments.  Synchronises the stream. */
+int goai_train_export(goai_ctx* ctx, int what, const char* const* names, float* const* tensors_host,
+                      const int64_t* numels, int n_tensors);
+
+/* A fresh optimiser (train.py:52 builds one per run): moments and step count to zero. */
+int goai_train_reset_optimizer(goai_ctx* ctx);
+
+/* One train_step on device arrays: states / next_states uint8 [n][6][S][S], wins float [n] (the
+ * replay's `wins`; the critic target is -wins as in ac_net.py:76), pi float [n][A] (the actor's
+ * target is argmax(pi)).  The caller has already built next_states = children[actions] under
+ * its random symmetries (ac_net.py:69-71, models/__init__.py:119).  The value net takes
+ * states = pi = NULL.  2 <= n <= max_batch.  metrics_host[4] (HOST): critic loss, critic
+ * accuracy, actor loss, actor accuracy (NaN for the value net's last two).  Every reduction
+ * runs in a fixed order: the same inputs give the same bits.  Synchronises the stream. */
+int goai_train_step(goai_ctx* ctx, const uint8_t* states, const uint8_t* next_states, const float* wins,
+                    const float* pi, int n, float lr, float weight_decay, float* metrics_host);
+
+/* The flat fp32 DEVICE buffer of all parameters (not the BatchNorm statistics), for
+ * average_model (/root/reference/go_ai/models/__init__.py:279-282): all-reduce it in place
+ * over the ranks (RCCL) and scale by 1 / world_size.  Same layout on every rank. */
+int goai_train_params(goai_ctx* ctx, float** params_device, int64_t* numel);
+
+/* Fold the trained parameters and statistics into this context's inference images (needs
+ * goai_nn_init with the same net kind and n_blocks): what goai_load_weights does, from the
+ * training buffers. */
+int goai_train_sync_inference(goai_ctx* ctx);
+
+/* ---------------------------------------------------------------------------------------
  * Measurement aid (no counterpart in the reference, which only logs seconds per game,
  * /root/reference/go_ai/utils.py:196-207): when enabled, every launch of the dominant kernel
  * (the 3x3 convolution) is bracketed by HIP events on the context's stream.

@@ -76,3 +76,52 @@ def test_bench_rejects_a_world_size_that_differs_from_gpus():
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo"],
                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=120)
     assert proc.returncode != 0 and "started 2 ranks" in proc.stderr
+
+
+def _avg_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "go-ai_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from go_ai import data
+    from go_ai.models import average_model
+
+    class Model:                      # what average_model needs of a net: its flat parameter buffer
+        def __init__(self):
+            self.flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
+
+        def flat_parameters(self):
+            return self.flat
+
+    comm, m = data.TorchComm(), Model()
+    average_model(comm, m)
+    metrics = comm.allreduce(np.array([1.0 + rank, np.nan if rank else 2.0])) / comm.Get_size()
+    scalar = comm.allreduce(3.0 * (rank + 1))
+    torch.save(dict(flat=m.flat, metrics=metrics, scalar=scalar), os.path.join(out_dir, f"a{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_average_model_world2(tmp_path):
+    """average_model (/root/reference/go_ai/models/__init__.py:279-282) and the metric all-reduce of optimize()
+    (models/__init__.py:226) over two gloo ranks."""
+    world, port = 2, 31500 + os.getpid() % 2000
+    mp.spawn(_avg_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"a{r}.pt"), weights_only=False) for r in range(world)]
+    for r in res:
+        assert torch.equal(r["flat"], torch.arange(10, dtype=torch.float32) * 1.5)
+        assert r["metrics"][0] == 1.5 and r["metrics"][1] != r["metrics"][1]      # nan + 2 stays nan, as with MPI.SUM
+        assert r["scalar"] == 9.0
+
+
+def test_solo_comm_and_metrics_text():
+    sys.path.insert(0, os.path.join(ROOT, "go-ai_amd"))
+    from go_ai import data
+    from go_ai.models import Adam, ModelMetrics, average_model
+    assert data.SoloComm().allreduce(4.5) == 4.5
+    average_model(data.SoloComm(), None)                  # one rank: nothing to do, the model is not touched
+    assert str(ModelMetrics(0.5, 0.25, float("nan"), None)) == "C[25.0% 0.500L] "
+    assert str(ModelMetrics(0.5, 0.25, 1.25, 0.5)) == "C[25.0% 0.500L] A[50.0% 1.250L] "
+    opt = Adam(lr=2e-3)
+    assert (opt.lr, opt.weight_decay) == (2e-3, 1e-4)
