@@ -51,8 +51,8 @@ int tr_wgrad(int S, const float* a_in, const float* dz, float* partial, float* d
 int tr_head_fwd(const float* a, const float* w, const float* b, const float* gamma, const float* beta, float* hz, float* mean,
                 float* invstd, float* run_mean, float* run_var, float* f, int M, int C, int P, hipStream_t st);
 int tr_head_bwd(const float* df, const float* f, const float* hz, const float* mean, const float* invstd, const float* gamma,
-                const float* a, const float* w, float* dgamma, float* dbeta, float* dw, float* db, float* dhz, float* dA, int M,
-                int C, int P, hipStream_t st);
+                const float* a, const float* w, float* partial, float* dgamma, float* dbeta, float* dw, float* db, float* dhz,
+                float* dA, int M, int C, int P, hipStream_t st);
 int tr_linear_fwd(const float* f, const float* W, const float* bias, float* out, int B, int O, int J, int relu, hipStream_t st);
 int tr_linear_bwd(const float* dout, const float* f, const float* W, const float* act_mask, float* dW, float* db, float* df, int B,
                   int O, int J, hipStream_t st);

@@ -289,7 +289,7 @@ int critic_pass(const Pass& p, const uint8_t* states, const float* wins, float w
                          256, p.st));
     TR_TRY(tr_linear_bwd(t.dh1, t.f, p.par(h + ".4.weight"), nullptr, p.grad(h + ".4.weight"), p.grad(h + ".4.bias"), t.df, p.n, 256,
                          p.P, p.st));
-    TR_TRY(tr_head_bwd(t.df, t.f, t.hz, p.mean(hb), p.invstd(hb), p.par(h + ".1.weight"), xl, p.par(h + ".0.weight"),
+    TR_TRY(tr_head_bwd(t.df, t.f, t.hz, p.mean(hb), p.invstd(hb), p.par(h + ".1.weight"), xl, p.par(h + ".0.weight"), t.col_partial,
                        p.grad(h + ".1.weight"), p.grad(h + ".1.bias"), p.grad(h + ".0.weight"), p.grad(h + ".0.bias"), t.dhz, t.g[0],
                        p.M, 1, p.P, p.st));
     return trunk_backward(p, states);
@@ -309,7 +309,7 @@ int actor_pass(const Pass& p, const uint8_t* states, const float* pi)
     TR_TRY(tr_actor_loss(t.logits, pi, t.dlogits, t.metrics, p.n, p.A, p.st));
     TR_TRY(tr_linear_bwd(t.dlogits, t.f, p.par(h + ".4.weight"), nullptr, p.grad(h + ".4.weight"), p.grad(h + ".4.bias"), t.df, p.n,
                          p.A, 2 * p.P, p.st));
-    TR_TRY(tr_head_bwd(t.df, t.f, t.hz, p.mean(hb), p.invstd(hb), p.par(h + ".1.weight"), xl, p.par(h + ".0.weight"),
+    TR_TRY(tr_head_bwd(t.df, t.f, t.hz, p.mean(hb), p.invstd(hb), p.par(h + ".1.weight"), xl, p.par(h + ".0.weight"), t.col_partial,
                        p.grad(h + ".1.weight"), p.grad(h + ".1.bias"), p.grad(h + ".0.weight"), p.grad(h + ".0.bias"), t.dhz, t.g[0],
                        p.M, 2, p.P, p.st));
     return trunk_backward(p, states);

@@ -95,23 +95,27 @@ __global__ __launch_bounds__(256) void k_tr_relayout(const float* __restrict__ w
 
 // ---- column reductions over [M][128] in a fixed order ----------------------------------------------------------------
 // grid = slices; block = 2 x 128 threads (two row phases per channel); partial[slice][k][128], k < NOUT
-enum { TR_SUM = 0, TR_SQDEV = 1, TR_BNGRAD = 2 };
+enum { TR_SUM = 0, TR_SQDEV = 1, TR_BNGRAD = 2, TR_WEIGHTED = 3 };
 
+// TR_WEIGHTED: partial[.][k][c] = sum_rows x[row][c] * a[row * wc + k], k < wc <= 2 (the head convolution's weight gradient)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_tr_colreduce(const float* __restrict__ x, const float* __restrict__ a,
                                                       const float* __restrict__ z, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, float* __restrict__ partial, int M,
-                                                      int rows_per_slice)
+                                                      int rows_per_slice, int wc)
 {
     __shared__ float red[2][2][128];
     const int c = threadIdx.x & 127, h = threadIdx.x >> 7;
     const int r0 = blockIdx.x * rows_per_slice, r1 = min(M, r0 + rows_per_slice);
     float s0 = 0.0f, s1 = 0.0f;
-    const float mu = (MODE != TR_SUM) ? mean[c] : 0.0f, is = (MODE == TR_BNGRAD) ? invstd[c] : 0.0f;
+    const float mu = (MODE == TR_SQDEV || MODE == TR_BNGRAD) ? mean[c] : 0.0f, is = (MODE == TR_BNGRAD) ? invstd[c] : 0.0f;
     for (int r = r0 + h; r < r1; r += 2) {
         const size_t i = (size_t)r * 128 + c;
         if (MODE == TR_SUM) s0 += x[i];
-        else if (MODE == TR_SQDEV) { const float d = x[i] - mu; s0 = fmaf(d, d, s0); }
+        else if (MODE == TR_WEIGHTED) {
+            s0 = fmaf(x[i], a[r * wc], s0);
+            if (wc > 1) s1 = fmaf(x[i], a[r * wc + 1], s1);
+        } else if (MODE == TR_SQDEV) { const float d = x[i] - mu; s0 = fmaf(d, d, s0); }
         else {
             const float dm = a[i] > 0.0f ? x[i] : 0.0f;          // ReLU backward fused in
             s0 += dm;
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(128) void k_tr_mean_final(const float* __restrict__
 {
     const int c = threadIdx.x;
     float s = 0.0f;
+#pragma unroll 8
     for (int k = 0; k < slices; k++) s += partial[((size_t)k * 2) * 128 + c];
     mean[c] = s / (float)M;
 }
@@ -142,6 +147,7 @@ __global__ __launch_bounds__(128) void k_tr_var_final(const float* __restrict__ 
 {
     const int c = threadIdx.x;
     float s = 0.0f;
+#pragma unroll 8
     for (int k = 0; k < slices; k++) s += partial[((size_t)k * 2) * 128 + c];
     const float var = s / (float)M;
     invstd[c] = 1.0f / sqrtf(var + BN_EPS);
@@ -154,6 +160,7 @@ __global__ __launch_bounds__(128) void k_tr_bngrad_final(const float* __restrict
 {
     const int c = threadIdx.x;
     float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll 8
     for (int k = 0; k < slices; k++) {
         s0 += partial[((size_t)k * 2) * 128 + c];
         s1 += partial[((size_t)k * 2 + 1) * 128 + c];
@@ -163,10 +170,20 @@ __global__ __launch_bounds__(128) void k_tr_bngrad_final(const float* __restrict
     dgamma[c] += s1;
     dbeta[c] += s0;
 }
+__global__ __launch_bounds__(256) void k_tr_headw_final(const float* __restrict__ partial, int slices, float* __restrict__ dw, int wc)
+{
+    const int c = threadIdx.x & 127, k = threadIdx.x >> 7;
+    if (k >= wc) return;
+    float s = 0.0f;
+#pragma unroll 8
+    for (int j = 0; j < slices; j++) s += partial[((size_t)j * 2 + k) * 128 + c];
+    dw[k * 128 + c] += s;
+}
 __global__ __launch_bounds__(128) void k_tr_sum_final(const float* __restrict__ partial, int slices, float* __restrict__ dst)
 {
     const int c = threadIdx.x;
     float s = 0.0f;
+#pragma unroll 8
     for (int k = 0; k < slices; k++) s += partial[((size_t)k * 2) * 128 + c];
     dst[c] += s;
 }
@@ -252,6 +269,7 @@ __global__ __launch_bounds__(256) void k_tr_wgrad_reduce(const float* __restrict
     if (i >= 9 * 128 * 128) return;
     const int ci = i & 127, co = (i >> 7) & 127, tap = i >> 14;
     float s = 0.0f;
+#pragma unroll 8
     for (int k = 0; k < slices; k++) s += partial[(size_t)k * 9 * 128 * 128 + i];
     dw[((size_t)co * 128 + ci) * 9 + tap] += s;
 }
@@ -318,7 +336,7 @@ __global__ __launch_bounds__(1024) void k_tr_head_bn_bwd(const float* __restrict
                                                          const float* __restrict__ hz, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                         float* __restrict__ dhz, int M, int C, int P)
+                                                         float* __restrict__ dbias, float* __restrict__ dhz, int M, int C, int P)
 {
     __shared__ float red[1024];
     for (int c = 0; c < C; c++) {
@@ -335,29 +353,19 @@ __global__ __launch_bounds__(1024) void k_tr_head_bn_bwd(const float* __restrict
         s1 = block_sum_1024(s1, red);
         if (threadIdx.x == 0) { dgamma[c] += s1; dbeta[c] += s0; }
         const float inv_m = 1.0f / (float)M;
+        float sb = 0.0f;
         for (int r = threadIdx.x; r < M; r += 1024) {
             const int b = r / P, p = r - b * P;
             const size_t j = (size_t)b * C * P + c * P + p;
             const float dm = f[j] > 0.0f ? df[j] : 0.0f;
             const float xh = (hz[r * C + c] - mu) * is;
-            dhz[r * C + c] = gamma[c] * is * (dm - s0 * inv_m - xh * s1 * inv_m);
+            const float v = gamma[c] * is * (dm - s0 * inv_m - xh * s1 * inv_m);
+            dhz[r * C + c] = v;
+            sb += v;
         }
+        sb = block_sum_1024(sb, red);        // the 1x1 convolution's bias gradient (zero in exact arithmetic)
+        if (threadIdx.x == 0) dbias[c] += sb;
     }
-}
-
-// dw[c][k] += sum_rows dhz[row][c] * a[row][k]; db[c] += sum_rows dhz[row][c]: one workgroup per head channel
-__global__ __launch_bounds__(128) void k_tr_head_conv_bwd_w(const float* __restrict__ dhz, const float* __restrict__ a,
-                                                            float* __restrict__ dw, float* __restrict__ db, int M, int C)
-{
-    const int c = blockIdx.x, k = threadIdx.x;
-    float s = 0.0f, sb = 0.0f;
-    for (int r = 0; r < M; r++) {
-        const float d = dhz[r * C + c];
-        s = fmaf(d, a[(size_t)r * 128 + k], s);
-        sb += d;
-    }
-    dw[c * 128 + k] += s;
-    if (k == 0) db[c] += sb;
 }
 
 // dA[row][k] = sum_c dhz[row][c] * w[c][k]: the gradient that enters the trunk from this head
@@ -513,9 +521,9 @@ int tr_bn_stats(const float* z, float* partial, float* mean, float* invstd, floa
 {
     int rps;
     const int sl = tr_slices(M, rps);
-    k_tr_colreduce<TR_SUM><<<sl, 256, 0, st>>>(z, nullptr, nullptr, nullptr, nullptr, partial, M, rps);
+    k_tr_colreduce<TR_SUM><<<sl, 256, 0, st>>>(z, nullptr, nullptr, nullptr, nullptr, partial, M, rps, 0);
     k_tr_mean_final<<<1, 128, 0, st>>>(partial, sl, M, mean);
-    k_tr_colreduce<TR_SQDEV><<<sl, 256, 0, st>>>(z, nullptr, nullptr, mean, nullptr, partial, M, rps);
+    k_tr_colreduce<TR_SQDEV><<<sl, 256, 0, st>>>(z, nullptr, nullptr, mean, nullptr, partial, M, rps, 0);
     k_tr_var_final<<<1, 128, 0, st>>>(partial, sl, M, mean, invstd, run_mean, run_var);
     TR_CHECK();
 }
@@ -530,7 +538,7 @@ int tr_bn_bwd(const float* d, const float* a, const float* z, const float* mean,
 {
     int rps;
     const int sl = tr_slices(M, rps);
-    k_tr_colreduce<TR_BNGRAD><<<sl, 256, 0, st>>>(d, a, z, mean, invstd, partial, M, rps);
+    k_tr_colreduce<TR_BNGRAD><<<sl, 256, 0, st>>>(d, a, z, mean, invstd, partial, M, rps, 0);
     k_tr_bngrad_final<<<1, 128, 0, st>>>(partial, sl, sums, dgamma, dbeta);
     k_tr_bn_bwd<<<nblk((long)M * 128), 256, 0, st>>>(d, a, z, mean, invstd, gamma, sums, dz, dres, (long)M * 128, 1.0f / (float)M);
     TR_CHECK();
@@ -539,7 +547,7 @@ int tr_colsum_add(const float* x, float* partial, float* dst, int M, hipStream_t
 {
     int rps;
     const int sl = tr_slices(M, rps);
-    k_tr_colreduce<TR_SUM><<<sl, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, partial, M, rps);
+    k_tr_colreduce<TR_SUM><<<sl, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, partial, M, rps, 0);
     k_tr_sum_final<<<1, 128, 0, st>>>(partial, sl, dst);
     TR_CHECK();
 }
@@ -559,11 +567,14 @@ int tr_head_fwd(const float* a, const float* w, const float* b, const float* gam
     TR_CHECK();
 }
 int tr_head_bwd(const float* df, const float* f, const float* hz, const float* mean, const float* invstd, const float* gamma,
-                const float* a, const float* w, float* dgamma, float* dbeta, float* dw, float* db, float* dhz, float* dA, int M,
-                int C, int P, hipStream_t st)
+                const float* a, const float* w, float* partial, float* dgamma, float* dbeta, float* dw, float* db, float* dhz,
+                float* dA, int M, int C, int P, hipStream_t st)
 {
-    k_tr_head_bn_bwd<<<1, 1024, 0, st>>>(df, f, hz, mean, invstd, gamma, dgamma, dbeta, dhz, M, C, P);
-    k_tr_head_conv_bwd_w<<<C, 128, 0, st>>>(dhz, a, dw, db, M, C);
+    int rps;
+    const int sl = tr_slices(M, rps);
+    k_tr_head_bn_bwd<<<1, 1024, 0, st>>>(df, f, hz, mean, invstd, gamma, dgamma, dbeta, db, dhz, M, C, P);
+    k_tr_colreduce<TR_WEIGHTED><<<sl, 256, 0, st>>>(a, dhz, nullptr, nullptr, nullptr, partial, M, rps, C);
+    k_tr_headw_final<<<1, 256, 0, st>>>(partial, sl, dw, C);
     k_tr_head_conv_bwd_x<<<nblk((long)M * 128), 256, 0, st>>>(dhz, w, dA, M, C);
     TR_CHECK();
 }
