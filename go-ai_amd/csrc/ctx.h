@@ -22,6 +22,14 @@ struct goai_ctx {
     goai::Tree tree;
     goai::Train train;
 
+    // undo the allocations made since the marks (a failed *_init)
+    void release_from(size_t mark, size_t host_mark)
+    {
+        while (allocs.size() > mark) { (void)hipFree(allocs.back()); allocs.pop_back(); }
+        while (host_allocs.size() > host_mark) { (void)hipHostFree(host_allocs.back()); host_allocs.pop_back(); }
+        (void)hipGetLastError();   // the failure was reported by the init call; do not leave it for the next launch check
+    }
+
     void release()
     {
         for (void* p : allocs) (void)hipFree(p);

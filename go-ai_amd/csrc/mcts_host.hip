@@ -24,9 +24,23 @@ static int state_words(int S)
     return 3 * ((P + 63) / 64) + 1;
 }
 
+static int mcts_init_impl(goai_ctx* c, int n_games, int max_sims, int mode);
+
+// A failed init leaves the context as it was (its partial allocations are freed), so it can be retried.
 int mcts_init(goai_ctx* c, int n_games, int max_sims, int mode)
 {
     GOAI_REQUIRE(c->tree.n_games == 0, "goai_mcts_init was already called on this context");
+    const size_t mark = c->allocs.size(), host_mark = c->host_allocs.size();
+    const int rc = mcts_init_impl(c, n_games, max_sims, mode);
+    if (rc) {
+        c->release_from(mark, host_mark);
+        c->tree = Tree();
+    }
+    return rc;
+}
+
+static int mcts_init_impl(goai_ctx* c, int n_games, int max_sims, int mode)
+{
     GOAI_REQUIRE(n_games > 0, "n_games must be positive");
     // numpy's pairwise mean is maintained incrementally for up to 128 values per node
     GOAI_REQUIRE(max_sims >= 0 && max_sims <= 128, "max_sims must be in [0, 128]");
@@ -82,10 +96,12 @@ int mcts_reset(goai_ctx* c, const uint8_t* roots)
 {
     REQUIRE_TREE(c);
     GOAI_REQUIRE(roots != nullptr, "root_states is NULL");
+    const int rc = launch_mcts_reset(c->S, c->tree, roots, c->stream);
+    if (rc) return rc;
     c->tree.steps_since_reset = 0;
     c->tree.pending_select = false;
     c->tree.pending_expand = 0;
-    return launch_mcts_reset(c->S, c->tree, roots, c->stream);
+    return GOAI_OK;
 }
 
 int mcts_select(goai_ctx* c, uint8_t* leaf_states_out)
@@ -97,9 +113,11 @@ int mcts_select(goai_ctx* c, uint8_t* leaf_states_out)
         set_error("more than max_sims + 1 search steps since the last reset/advance");
         return GOAI_ERR_STATE;
     }
+    const int rc = launch_mcts_select(c->S, t, leaf_states_out, c->stream);
+    if (rc) return rc;                      // the state flags move only once the launch is in the stream
     t.pending_select = true;
     t.pending_expand = t.mode == GOAI_SEARCH_Q ? 1 : 0;
-    return launch_mcts_select(c->S, t, leaf_states_out, c->stream);
+    return GOAI_OK;
 }
 
 // Q mode, between select and backup: node.make_children() for every non-terminal leaf
@@ -114,10 +132,11 @@ int mcts_expand(goai_ctx* c, uint8_t* children_out, uint8_t* valid_out)
         set_error("goai_mcts_expand must follow goai_mcts_select");
         return GOAI_ERR_STATE;
     }
-    t.pending_expand = 2;
     int rc;
     if ((rc = launch_q_scan(t, c->stream))) return rc;
-    return launch_q_expand(c->S, t, children_out, valid_out, c->stream);
+    if ((rc = launch_q_expand(c->S, t, children_out, valid_out, c->stream))) return rc;
+    t.pending_expand = 2;
+    return GOAI_OK;
 }
 
 int mcts_backup_q(goai_ctx* c, const double* leaf_val, const double* child_vals, int raw)
@@ -130,10 +149,12 @@ int mcts_backup_q(goai_ctx* c, const double* leaf_val, const double* child_vals,
         return GOAI_ERR_STATE;
     }
     GOAI_REQUIRE((leaf_val != nullptr) == (child_vals != nullptr), "pass both leaf_val and child_vals, or neither");
+    const int rc = launch_q_backup(c->S, t, leaf_val, child_vals, raw, c->stream);
+    if (rc) return rc;
     t.pending_select = false;
     t.pending_expand = 0;
     t.steps_since_reset++;
-    return launch_q_backup(c->S, t, leaf_val, child_vals, raw, c->stream);
+    return GOAI_OK;
 }
 
 int mcts_backup(goai_ctx* c, const float* pi_logits, const float* prior, const float* val, int raw)
@@ -144,9 +165,11 @@ int mcts_backup(goai_ctx* c, const float* pi_logits, const float* prior, const f
     if (!t.pending_select) { set_error("goai_mcts_backup without a preceding goai_mcts_select"); return GOAI_ERR_STATE; }
     GOAI_REQUIRE(val != nullptr, "val_logits is NULL");
     GOAI_REQUIRE((pi_logits != nullptr) != (prior != nullptr), "pass exactly one of pi_logits / prior");
+    const int rc = launch_mcts_backup(c->S, t, pi_logits, prior, val, raw, c->stream);
+    if (rc) return rc;
     t.pending_select = false;
     t.steps_since_reset++;
-    return launch_mcts_backup(c->S, t, pi_logits, prior, val, raw, c->stream);
+    return GOAI_OK;
 }
 
 // n_steps x mct_step with the context's own network (mct_search = 1 + n_sims of them).
@@ -186,10 +209,12 @@ int mcts_advance(goai_ctx* c, const int32_t* actions)
 {
     REQUIRE_ROOTS(c);
     GOAI_REQUIRE(actions != nullptr, "actions is NULL");
+    const int rc = launch_mcts_advance(c->S, c->tree, actions, 2 * c->P, c->stream);
+    if (rc) return rc;
     c->tree.steps_since_reset = 0;
     c->tree.pending_select = false;
     c->tree.pending_expand = 0;
-    return launch_mcts_advance(c->S, c->tree, actions, 2 * c->P, c->stream);
+    return GOAI_OK;
 }
 
 }  // namespace goai

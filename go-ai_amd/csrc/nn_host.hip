@@ -40,12 +40,26 @@ static uint16_t bf16_rne(float f)
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
+static int nn_init_impl(goai_ctx* c, int kind, int layers, int max_batch, int dtype);
+
+// A failed init leaves the context as it was (its partial allocations are freed), so it can be retried.
 int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
 {
     GOAI_REQUIRE(kind == 0 || kind == 1, "net_kind must be 0 (actor-critic) or 1 (value)");
     GOAI_REQUIRE(layers >= 0 && layers <= 64, "n_blocks out of range");
     GOAI_REQUIRE(max_batch > 0, "max_batch must be positive");
     GOAI_REQUIRE(c->net.kind < 0, "goai_nn_init was already called on this context");
+    const size_t mark = c->allocs.size(), host_mark = c->host_allocs.size();
+    const int rc = nn_init_impl(c, kind, layers, max_batch, dtype);
+    if (rc) {
+        c->release_from(mark, host_mark);
+        c->net = Net();
+    }
+    return rc;
+}
+
+static int nn_init_impl(goai_ctx* c, int kind, int layers, int max_batch, int dtype)
+{
     Net& n = c->net;
     n.kind = kind;
     n.layers = layers;

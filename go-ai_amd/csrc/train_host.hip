@@ -45,14 +45,28 @@ static void add_conv_bn(Train& t, const std::string& conv, const std::string& bn
 
 static std::string block_prefix(int i) { return "main." + std::to_string(3 + i) + ".main."; }
 
+static int train_init_impl(goai_ctx* c, int kind, int layers, int max_batch);
+
+// A failed init leaves the context as it was (its partial allocations are freed), so it can be retried.
 int train_init(goai_ctx* c, int kind, int layers, int max_batch)
 {
     GOAI_REQUIRE(kind == 0 || kind == 1, "net_kind must be 0 (actor-critic) or 1 (value)");
     GOAI_REQUIRE(layers >= 0 && layers <= 64, "n_blocks out of range");
     GOAI_REQUIRE(max_batch > 1, "max_batch must be at least 2 (BatchNorm needs a batch)");
     GOAI_REQUIRE((long)max_batch * c->P * 128 < (1L << 31), "max_batch * board cells too large");
+    GOAI_REQUIRE(!c->train.ready && c->train.kind < 0, "goai_train_init was already called on this context");
+    const size_t mark = c->allocs.size(), host_mark = c->host_allocs.size();
+    const int rc = train_init_impl(c, kind, layers, max_batch);
+    if (rc) {
+        c->release_from(mark, host_mark);
+        c->train = Train();
+    }
+    return rc;
+}
+
+static int train_init_impl(goai_ctx* c, int kind, int layers, int max_batch)
+{
     Train& t = c->train;
-    GOAI_REQUIRE(!t.ready && t.kind < 0, "goai_train_init was already called on this context");
     t.kind = kind;
     t.layers = layers;
     t.max_batch = max_batch;

@@ -92,3 +92,25 @@ def test_finished_games_stay_finished_and_are_not_counted():
     assert (moves2[:3] == 2).all() and (result2[:3] == 0).all() and (moves2[3:] == 3).all()
     assert c.mcts_counters()["errors"] == 0
     c.close()
+
+
+def test_failed_init_can_be_retried():
+    """An init that runs out of device memory frees what it had allocated and leaves the context as it was: the same
+    call with a size that fits then succeeds, and the context works."""
+    from go_ai import _hip
+    from go_ai.engine import Context
+    c = Context(19)
+    with pytest.raises(_hip.GoaiError):
+        c.mcts_init(1 << 24, 128)                        # ~2^24 games x 130 nodes x 362 actions: terabytes
+    with pytest.raises(_hip.GoaiError):
+        c.nn_init(Context.NET_AC, 3, 1 << 22)            # 3 activation buffers of 2^22 x 361 x 128 floats
+    with pytest.raises(_hip.GoaiError):
+        c.train_init(Context.NET_AC, 64, 40000)          # 260 activation buffers of 40000 x 361 x 128 floats
+    c.nn_init(Context.NET_AC, 1, 4)
+    c.load_weights(nn_ref.make_state_dict("ac", 19, 1, layers=1))
+    c.mcts_init(4, 3)
+    c.train_init(Context.NET_AC, 1, 4)
+    c.mcts_reset(np.zeros((4, 6, 19, 19), np.uint8))
+    c.mcts_run(3)
+    assert int(c.mcts_readout()[0].sum()) == 4 * 3 and c.mcts_counters()["errors"] == 0
+    c.close()
