@@ -237,6 +237,9 @@ def main():
     ap.add_argument("--groups", type=int, default=1, help="independent game groups on separate HIP streams")
     ap.add_argument("--no-refill", action="store_true",
                     help="leave the slot of a finished game idle instead of starting the next game in it")
+    ap.add_argument("--c-gather", action="store_true",
+                    help="also sum the per-rank results with the C-ABI's own RCCL all-reduce (goai_gather_stats) and "
+                         "check it against the torch.distributed gather")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: CPU rehearsal of the N-rank launch / rendezvous / gather path with a stub body (no GPU)")
     args = ap.parse_args()
@@ -355,6 +358,18 @@ def main():
     tot = reduce_stats(per_rank)
     total_evals, t_max = tot["leaf_evals"], tot["seconds"]
 
+    c_gather = None
+    if args.c_gather and len(sp.groups) == 1:
+        # the same sums through goai_gather_stats: rank 0's RCCL id goes round by torch.distributed, the all-reduce is the library's
+        ident = [sp.ctx.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        comm = sp.ctx.comm_init(ident[0], world, rank)
+        sums, extra = sp.ctx.gather_stats(comm, extra=[float(my_evals), float(st["games"])])
+        sp.ctx.comm_destroy(comm)
+        assert int(extra[0]) == int(total_evals) and int(extra[1]) == int(tot["games"]), (extra, tot)
+        c_gather = dict(sums, ranks=world, leaf_evals_timed=int(extra[0]), games=int(extra[1]))
+
     if rank == 0:
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "conv3x3_traffic.json")
@@ -370,6 +385,7 @@ def main():
             "ms_per_step": round(t_max / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
+            **({"c_gather": c_gather} if c_gather else {}),
             "precision": {"f32": "fp32 storage and arithmetic (fp32 MFMA)",
                           "bf16x6": "fp32 storage; trunk products as 6 bf16 MFMAs on operands split exactly into three bf16 parts, "
                                     "fp32 accumulate and transforms: 6e-6 max rel. error vs the torch fp32 oracle on the 3-block net "

@@ -415,6 +415,26 @@ int goai_train_sync_inference(goai_ctx* ctx)
     return train_sync_inference(ctx);
 }
 
+int goai_comm_unique_id(void* id_host) { return comm_unique_id(id_host); }
+
+int goai_comm_init(goai_ctx* ctx, const void* id_host, int n_ranks, int rank, void** rccl_comm_out)
+{
+    CTX_ENTER(ctx);
+    return comm_init(ctx, id_host, n_ranks, rank, rccl_comm_out);
+}
+
+int goai_comm_destroy(goai_ctx* ctx, void* rccl_comm)
+{
+    CTX_ENTER(ctx);
+    return comm_destroy(ctx, rccl_comm);
+}
+
+int goai_gather_stats(goai_ctx* ctx, void* rccl_comm, double* extra_inout_host, int n_extra, int64_t* totals_host)
+{
+    CTX_ENTER(ctx);
+    return gather_stats(ctx, rccl_comm, extra_inout_host, n_extra, totals_host);
+}
+
 int goai_profile_enable(goai_ctx* ctx, int enable)
 {
     CTX_ENTER(ctx);

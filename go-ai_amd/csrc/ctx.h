@@ -21,6 +21,7 @@ struct goai_ctx {
     std::vector<hipEvent_t> prof_events;   // start/stop pairs
     goai::Tree tree;
     goai::Train train;
+    void* gather_buf = nullptr;   // device staging of goai_gather_stats (in allocs)
 
     // undo the allocations made since the marks (a failed *_init)
     void release_from(size_t mark, size_t host_mark)

@@ -63,6 +63,12 @@ int train_step(goai_ctx* c, const uint8_t* states, const uint8_t* next_states, c
                float weight_decay, float* metrics_host);
 int train_sync_inference(goai_ctx* c);
 
+// ---- result gather over ranks (gather.hip) ----
+int comm_unique_id(void* id128_host);
+int comm_init(goai_ctx* c, const void* id128_host, int n_ranks, int rank, void** comm_out);
+int comm_destroy(goai_ctx* c, void* comm);
+int gather_stats(goai_ctx* c, void* comm, double* extra_inout_host, int n_extra, int64_t* totals_host);
+
 // ---- search (mcts_host.hip) ----
 int mcts_init(goai_ctx* c, int n_games, int max_sims, int mode);
 int mcts_reset(goai_ctx* c, const uint8_t* roots);

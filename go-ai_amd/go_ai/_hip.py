@@ -73,6 +73,10 @@ _SIGNATURES = {
                         ctypes.POINTER(ctypes.c_float)],
     "goai_train_params": [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64)],
     "goai_train_sync_inference": [c_void_p],
+    "goai_comm_unique_id": [c_void_p],
+    "goai_comm_init": [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)],
+    "goai_comm_destroy": [c_void_p, c_void_p],
+    "goai_gather_stats": [c_void_p, c_void_p, ctypes.POINTER(c_double), c_int, ctypes.POINTER(c_int64)],
     "goai_profile_enable": [c_void_p, c_int],
     "goai_profile_read": [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64)],
 }

@@ -154,6 +154,35 @@ class Context:
         c_numels = (ctypes.c_int64 * n)(*[a.size for a in arrays])
         _hip.check(_hip.lib.goai_load_weights(self._h, c_names, c_ptrs, c_numels, n))
 
+    # ---- result gather over ranks (goai_gather_stats) --------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes from rank 0 (ncclGetUniqueId) to be handed to every rank's comm_init."""
+        buf = ctypes.create_string_buffer(128)
+        _hip.check(_hip.lib.goai_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, n_ranks, rank):
+        self._bind()
+        comm = ctypes.c_void_p()
+        _hip.check(_hip.lib.goai_comm_init(self._h, ctypes.c_char_p(bytes(unique_id)), int(n_ranks), int(rank), ctypes.byref(comm)))
+        return comm
+
+    def comm_destroy(self, comm):
+        _hip.check(_hip.lib.goai_comm_destroy(self._h, comm))
+
+    GATHER_FIELDS = ("finished", "black_wins", "white_wins", "finished_moves", "leaf_evals", "transitions", "errors", "forwards")
+
+    def gather_stats(self, comm=None, extra=()):
+        """Sums over the communicator's ranks (utils.py:201-204) of this context's game statistics and search counters,
+        plus the caller's own additive figures `extra`.  Returns (dict of GATHER_FIELDS, list of summed extras)."""
+        self._bind()
+        n = len(extra)
+        ex = (ctypes.c_double * max(n, 1))(*[float(x) for x in extra])
+        tot = (ctypes.c_int64 * 8)()
+        _hip.check(_hip.lib.goai_gather_stats(self._h, comm, ex if n else None, n, tot))
+        return dict(zip(self.GATHER_FIELDS, [int(x) for x in tot])), [float(ex[i]) for i in range(n)]
+
     # ---- optimisation step (include/goai_hip.h: goai_train_*) ---------------------------
     @staticmethod
     def _tensor_table(items):

@@ -354,6 +354,30 @@ int goai_train_params(goai_ctx* ctx, float** params_device, int64_t* numel);
 int goai_train_sync_inference(goai_ctx* ctx);
 
 /* ---------------------------------------------------------------------------------------
+ * The one collective of the path: the end-of-run sums over ranks that the reference makes with
+ * comm.allreduce(..., op=MPI.SUM) (/root/reference/go_ai/utils.py:201-204: seconds per game, win
+ * rates, steps).  Games are sharded over GPUs and the search never communicates; this is an RCCL
+ * all-reduce of a few numbers on the context's stream.  RCCL is loaded at run time (the copy
+ * already in the process, e.g. PyTorch's, else the system's); the library has no link-time
+ * dependency on it.
+ * ------------------------------------------------------------------------------------- */
+#define GOAI_COMM_ID_BYTES 128
+#define GOAI_GATHER_MAX_EXTRA 64
+/* ncclGetUniqueId: rank 0 calls this and hands the 128 bytes to the other ranks by any means. */
+int goai_comm_unique_id(void* id_host);
+/* ncclCommInitRank on the context's GPU: a communicator of n_ranks ranks (one process per GPU). */
+int goai_comm_init(goai_ctx* ctx, const void* id_host, int n_ranks, int rank, void** rccl_comm_out);
+int goai_comm_destroy(goai_ctx* ctx, void* rccl_comm);
+/* totals_host[8] (HOST): the sums over all ranks of goai_mcts_game_stats ([0] games finished,
+ * [1] black wins, [2] white wins, [3] moves played) and goai_mcts_counters ([4] leaf evaluations,
+ * [5] transitions, [6] errors, [7] states through the value net) of this context's search.
+ * extra_inout_host[n_extra] (HOST doubles, n_extra <= GOAI_GATHER_MAX_EXTRA, may be NULL/0): the
+ * caller's own additive figures (seconds, first-player wins ...), summed over ranks in place.
+ * rccl_comm: an ncclComm_t made by goai_comm_init (or by the same RCCL library); NULL = one rank,
+ * the local figures.  Every rank of the communicator must call it.  Synchronises the stream. */
+int goai_gather_stats(goai_ctx* ctx, void* rccl_comm, double* extra_inout_host, int n_extra, int64_t* totals_host);
+
+/* ---------------------------------------------------------------------------------------
  * Measurement aid (no counterpart in the reference, which only logs seconds per game,
  * /root/reference/go_ai/utils.py:196-207): when enabled, every launch of the dominant kernel
  * (the 3x3 convolution) is bracketed by HIP events on the context's stream.
