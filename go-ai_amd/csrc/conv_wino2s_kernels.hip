@@ -240,29 +240,44 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     // epilogue.  The products are formed transposed (A operand = weights, B operand = V), so in the C/D layout of
     // a 16x16 tile (col = lane & 15, row = 4 * (lane >> 4) + reg) a lane holds FOUR CONSECUTIVE output channels
     // of ONE wtile: one 16-byte load / store per output cell.
-    auto finish = [&](const f32x4 yv, const f32x4 bv, int y, int x, long board, int c0) {
-        if (y < S && x < S) {
-            const long off = (board * P + y * S + x) * 128 + c0;
-            f32x4 v = yv + bv;
-            if (RESID) v += *reinterpret_cast<const f32x4*>(&resid[off]);
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
-            *reinterpret_cast<f32x4*>(&out[off]) = v;
-        }
-    };
+    // The residual of a whole group of tiles is requested before the first store (off-board cells read the lane's
+    // first cell instead: no branch around a load), so the loads' latency is paid once per group, not once per cell.
     const int col = wave * 16 + 4 * lq;
     const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col]);
+    constexpr int GT = 4;                                    // tiles per group: 16 loads in flight
 #pragma unroll
-    for (int t = 0; t < MT; t++) {
-        const int w = t * 16 + li;
-        const int bl = w / W::T2, rem = w - bl * W::T2;
-        const long board = b_first + bl;
-        if (w >= W::WT || board >= nboards) continue;
-        const int ty = rem / W::T, tx = rem - ty * W::T;
+    for (int t0 = 0; t0 < MT; t0 += GT) {
+        long off[GT][4];
+        bool ok[GT][4];
+        f32x4 rv[GT][4];
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int g = 0; g < GT; g++) {
+            const int t = t0 + g;
+            const int w = t * 16 + li;
+            const int bl = w / W::T2, rem = w - bl * W::T2;
+            const long board = b_first + bl;
+            const bool tile_ok = t < MT && w < W::WT && board < nboards;
+            const int ty = rem / W::T, tx = rem - ty * W::T;
 #pragma unroll
-            for (int j = 0; j < 2; j++) finish(Y[i][j][t], bv, 2 * ty + i, 2 * tx + j, board, col);
+            for (int ij = 0; ij < 4; ij++) {
+                const int y = 2 * ty + (ij >> 1), x = 2 * tx + (ij & 1);
+                ok[g][ij] = tile_ok && y < S && x < S;
+                off[g][ij] = ok[g][ij] ? (board * P + y * S + x) * 128 + col : (long)b_first * P * 128 + col;
+                if (RESID) rv[g][ij] = *reinterpret_cast<const f32x4*>(&resid[off[g][ij]]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GT; g++) {
+            if (t0 + g >= MT) continue;
+#pragma unroll
+            for (int ij = 0; ij < 4; ij++) {
+                f32x4 v = Y[ij >> 1][ij & 1][t0 + g] + bv;
+                if (RESID) v += rv[g][ij];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
+                if (ok[g][ij]) *reinterpret_cast<f32x4*>(&out[off[g][ij]]) = v;
+            }
+        }
     }
 }
 
