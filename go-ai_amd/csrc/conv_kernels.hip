@@ -53,12 +53,17 @@ struct ConvCfg {
     static constexpr int LDS_BYTES = (A_FLOATS + 2 * B_FLOATS) * 4;
 };
 
-template <int S, int RT, bool RESID>
+// SPLIT: blockIdx.y = one 32-channel chunk of the input; the workgroup walks that chunk's 9 stages only and
+// writes its raw partial sums to out + blockIdx.y * M * 128 (k_conv3x3_sum4 adds the four up in a fixed order).  For
+// batches whose row tiles alone cannot fill the chip (the training step at the reference's batch size).
+template <int S, int RT, bool RESID, bool SPLIT = false>
 __global__ __launch_bounds__(256, 3) void k_conv3x3(const float* __restrict__ in, const float* __restrict__ wt,
                                                     const float* __restrict__ bias, const float* __restrict__ resid,
-                                                    float* __restrict__ out, int M, float floor_v)
+                                                    float* __restrict__ out_base, int M, float floor_v)
 {
     using G = Geom<S>;
+    float* __restrict__ out = SPLIT ? out_base + (size_t)blockIdx.y * M * 128 : out_base;
+    const int s_begin = SPLIT ? blockIdx.y * 9 : 0, s_end = SPLIT ? s_begin + 9 : 4 * 9;
     using C = ConvCfg<S, RT>;
     __shared__ __attribute__((aligned(16))) float lds[C::A_FLOATS + 2 * C::B_FLOATS];
     float* As = lds;
@@ -151,8 +156,8 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3(const float* __restrict__ in
     };
     auto tap_off = [](int tap) { return (tap / 3 - 1) * S + (tap - (tap / 3) * 3 - 1); };
 
-    load_a(0);
-    load_b(0);
+    load_a(s_begin / 9);
+    load_b(s_begin);
     store_a();
     store_b(0);
     __syncthreads();
@@ -161,7 +166,6 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3(const float* __restrict__ in
     // each = one A fragment x 8 MFMAs.  The A fragments of steps i+1 and i+2 are in flight while
     // step i computes -- across stage boundaries too, as long as the A image stays (same chunk).
     constexpr int NSTEP = 2 * RT;
-    constexpr int NSTAGE = 4 * 9;
     f32x4 a[3];
     a[0] = a_frag(0, tap_off(0), 0, 0);
     a[1] = a_frag(0, tap_off(0), 1 % RT, 1 / RT);
@@ -170,9 +174,9 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3(const float* __restrict__ in
     // alone on the SIMD, exposing every LDS latency.  Rotating the issue priority per stage
     // gives each resident workgroup the same share, so they finish together.
     const int prio_slot = blockIdx.x / 256;
-    for (int s = 0; s < NSTAGE; s++) {
+    for (int s = s_begin; s < s_end; s++) {
         const int chunk = s / 9, tap = s - chunk * 9;
-        const int buf = s & 1;
+        const int buf = (s - s_begin) & 1;
 #ifndef ABL_NO_PRIO
         switch ((s + prio_slot) % 3) {
             case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -181,9 +185,9 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3(const float* __restrict__ in
         }
 #endif
 #ifndef ABL_NO_BLOAD
-        if (s + 1 < NSTAGE) load_b(s + 1);
+        if (s + 1 < s_end) load_b(s + 1);
 #endif
-        const bool next_chunk = (tap == 8) && (chunk + 1 < 4);
+        const bool next_chunk = (tap == 8) && (s + 1 < s_end);
         if (next_chunk) load_a(chunk + 1);
 
         const int toff = tap_off(tap), toff_next = tap_off(tap + 1);
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3(const float* __restrict__ in
             __builtin_amdgcn_sched_barrier(0);
         }
 #ifndef ABL_NO_BLOAD
-        if (s + 1 < NSTAGE) store_b(buf ^ 1);      // buf^1 was last read in stage s-1
+        if (s + 1 < s_end) store_b(buf ^ 1);       // buf^1 was last read in stage s-1
 #endif
         if (next_chunk) {
             __syncthreads();                        // everyone is done with this chunk's A image
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3(const float* __restrict__ in
             const f32x4 n0 = a[NSTEP % 3], n1 = a[(NSTEP + 1) % 3];
             a[0] = n0;
             a[1] = n1;
-        } else if (s + 1 < NSTAGE) {
+        } else if (s + 1 < s_end) {
             a[0] = a_frag(0, tap_off(0), 0, 0);
             a[1] = a_frag(0, tap_off(0), 1 % RT, 1 / RT);
         }
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3(const float* __restrict__ in
 #pragma unroll
     for (int tn = 0; tn < 2; tn++) {
         const int col = wave * 32 + tn * 16 + li;
-        const float bv = bias[col];
+        const float bv = SPLIT ? 0.0f : bias[col];
         if (full) {
             // batch all residual loads of this column strip, then all stores
             f32x4 rv[RT];
@@ -329,6 +333,19 @@ static void launch_s(int rt, const float* in, const float* wt, const float* bias
     }
 }
 
+// out[i] = p0[i] + p1[i] + p2[i] + p3[i] + bias[col] (+ resid[i]), four floats per thread
+__global__ __launch_bounds__(256) void k_conv3x3_sum4(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                      const float* __restrict__ resid, float* __restrict__ out, long n4, long stride4)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4* p = reinterpret_cast<const f32x4*>(partial);
+    f32x4 v = ((p[i] + p[i + stride4]) + p[i + 2 * stride4]) + p[i + 3 * stride4];
+    v += *reinterpret_cast<const f32x4*>(&bias[(i & 31) * 4]);
+    if (resid) v += reinterpret_cast<const f32x4*>(resid)[i];
+    reinterpret_cast<f32x4*>(out)[i] = v;
+}
+
 #ifdef GOAI_CONV_STAMPS
 extern "C" int goai_debug_conv_stamps(unsigned long long* host_out, int n)
 {
@@ -358,6 +375,21 @@ int launch_conv3x3_linear(int S_rt, const float* in, const float* wt, const floa
                           int M, hipStream_t st)
 {
     return launch_conv3x3_floor(S_rt, in, wt, bias, resid, out, M, -INFINITY, st);
+}
+
+// The same convolution (no ReLU) for batches of few rows: every workgroup takes one 32-channel chunk of the input
+// (4 x the workgroups, a quarter of the stages each) into `partial` [4][M][128]; the chunks are summed in a fixed order.
+// Rounds differently from launch_conv3x3_linear (another summation order): a caller uses one or the other per shape.
+int launch_conv3x3_linear_split(int S_rt, const float* in, const float* wt, const float* bias, const float* resid, float* out,
+                                float* partial, int M, hipStream_t st)
+{
+    constexpr int RT = 5;
+    const int grid = (M + 16 * RT - 1) / (16 * RT);
+    GOAI_DISPATCH_SIZE(S_rt, (k_conv3x3<S, RT, false, true><<<dim3(grid, 4), dim3(256), 0, st>>>(in, wt, nullptr, nullptr, partial, M, -INFINITY)));
+    const long n4 = (long)M * 32;
+    k_conv3x3_sum4<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st>>>(partial, bias, resid, out, n4, n4);
+    GOAI_HIP_CHECK(hipGetLastError());
+    return GOAI_OK;
 }
 
 }  // namespace goai

@@ -51,6 +51,8 @@ int launch_conv3x3(int S, const float* in, const float* wt, const float* bias, c
                    hipStream_t st);
 int launch_conv3x3_linear(int S, const float* in, const float* wt, const float* bias, const float* resid, float* out, int M,
                           hipStream_t st);
+int launch_conv3x3_linear_split(int S, const float* in, const float* wt, const float* bias, const float* resid, float* out,
+                                float* partial, int M, hipStream_t st);
 int launch_conv3x3_bf16(int S, const float* in, const void* wt_bf16, const float* bias, const float* resid, float* out,
                         int M, hipStream_t st);
 int wino_boards_per_wg(int S);

@@ -9,6 +9,7 @@
 
 namespace goai {
 
+constexpr int TR_SPLIT_ROWS = 10240;   // below this many rows the 128 -> 128 convolutions run split over input-channel chunks
 constexpr int TR_MAX_SLICES = 64;      // row slices of the deterministic reductions (partials, then an ordered sum)
 
 // one named tensor of the reference's state_dict inside the flat buffers
@@ -33,7 +34,7 @@ struct Train {
     std::vector<float*> y;              // [layers] mid-block activations
     float* g[4] = { nullptr, nullptr, nullptr, nullptr };   // gradient work buffers [M][128]
     float* bn_saved = nullptr;          // [2*layers+2][2][128]: batch mean / invstd per BatchNorm (last: the head's)
-    float *col_partial = nullptr, *bn_sums = nullptr, *wgrad_partial = nullptr;
+    float *col_partial = nullptr, *bn_sums = nullptr, *wgrad_partial = nullptr, *conv_partial = nullptr;
     float *hz = nullptr, *dhz = nullptr, *f = nullptr, *df = nullptr;   // head: [M][2], [B][2P]
     float *h1 = nullptr, *dh1 = nullptr, *logits = nullptr, *dlogits = nullptr, *metrics = nullptr;
 };

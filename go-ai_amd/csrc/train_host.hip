@@ -11,6 +11,7 @@
 // commutes, so the order autograd would have used does not matter).  BatchNorm running statistics move once per
 // forward pass, critic pass first, as in the reference.
 #include <cmath>
+#include <algorithm>
 #include <cstring>
 
 #include "ctx.h"
@@ -115,6 +116,7 @@ static int train_init_impl(goai_ctx* c, int kind, int layers, int max_batch)
     if ((rc = tr_alloc(c, &t.col_partial, (size_t)TR_MAX_SLICES * 2 * 128))) return rc;
     if ((rc = tr_alloc(c, &t.bn_sums, 2 * 128))) return rc;
     if ((rc = tr_alloc(c, &t.wgrad_partial, (size_t)TR_MAX_SLICES * img))) return rc;
+    if (layers > 0 && (rc = tr_alloc(c, &t.conv_partial, (size_t)4 * std::min<size_t>(max_batch * P, TR_SPLIT_ROWS) * 128))) return rc;
     const size_t B = max_batch;
     if ((rc = tr_alloc(c, &t.hz, B * P * 2)) || (rc = tr_alloc(c, &t.dhz, B * P * 2)) || (rc = tr_alloc(c, &t.f, B * P * 2)) ||
         (rc = tr_alloc(c, &t.df, B * P * 2)) || (rc = tr_alloc(c, &t.h1, B * 256)) || (rc = tr_alloc(c, &t.dh1, B * 256)) ||
@@ -229,6 +231,13 @@ Names trunk_names(int l)   // l = 0: conv0; l = 1 + 2 i / 2 + 2 i: first / secon
 
 #define TR_TRY(expr) do { const int _rc = (expr); if (_rc) return _rc; } while (0)
 
+// out = conv3x3(in) + bias (+ resid), no ReLU.  Few rows: split over the four input-channel chunks (4 x the workgroups).
+int conv_linear(const Pass& p, const float* in, const float* img, const float* bias, const float* resid, float* out)
+{
+    if (p.M < TR_SPLIT_ROWS) return launch_conv3x3_linear_split(p.S, in, img, bias, resid, out, p.t.conv_partial, p.M, p.st);
+    return launch_conv3x3_linear(p.S, in, img, bias, resid, out, p.M, p.st);
+}
+
 // statistics of z[l], then a = relu(bn(z[l]) (+ resid))
 int bn_layer_fwd(const Pass& p, int l, const float* resid, float* a)
 {
@@ -246,11 +255,9 @@ int trunk_forward(const Pass& p, const uint8_t* states)
     const size_t img = (size_t)9 * 128 * 128;
     for (int i = 0; i < t.layers; i++) {
         const int l1 = 1 + 2 * i, l2 = 2 + 2 * i;
-        TR_TRY(launch_conv3x3_linear(p.S, t.x[i], t.img_f + (size_t)(l1 - 1) * img, p.par(trunk_names(l1).conv + ".bias"), nullptr,
-                                     t.z[l1], p.M, p.st));
+        TR_TRY(conv_linear(p, t.x[i], t.img_f + (size_t)(l1 - 1) * img, p.par(trunk_names(l1).conv + ".bias"), nullptr, t.z[l1]));
         TR_TRY(bn_layer_fwd(p, l1, nullptr, t.y[i]));
-        TR_TRY(launch_conv3x3_linear(p.S, t.y[i], t.img_f + (size_t)(l2 - 1) * img, p.par(trunk_names(l2).conv + ".bias"), nullptr,
-                                     t.z[l2], p.M, p.st));
+        TR_TRY(conv_linear(p, t.y[i], t.img_f + (size_t)(l2 - 1) * img, p.par(trunk_names(l2).conv + ".bias"), nullptr, t.z[l2]));
         TR_TRY(bn_layer_fwd(p, l2, t.x[i], t.x[i + 1]));
     }
     return GOAI_OK;
@@ -275,12 +282,12 @@ int trunk_backward(const Pass& p, const uint8_t* states)
         TR_TRY(bn_layer_bwd(p, l2, t.g[0], t.x[i + 1], t.g[1], t.g[2]));
         TR_TRY(tr_wgrad(p.S, t.y[i], t.g[1], t.wgrad_partial, p.grad(n2.conv + ".weight"), p.M, p.st));
         TR_TRY(tr_colsum_add(t.g[1], t.col_partial, p.grad(n2.conv + ".bias"), p.M, p.st));
-        TR_TRY(launch_conv3x3_linear(p.S, t.g[1], t.img_d + (size_t)(l2 - 1) * img, t.zero128, nullptr, t.g[3], p.M, p.st));
+        TR_TRY(conv_linear(p, t.g[1], t.img_d + (size_t)(l2 - 1) * img, t.zero128, nullptr, t.g[3]));
         // y[i] = relu(bn(z[l1])): g[3] -> dz1 in g[1]
         TR_TRY(bn_layer_bwd(p, l1, t.g[3], t.y[i], t.g[1], nullptr));
         TR_TRY(tr_wgrad(p.S, t.x[i], t.g[1], t.wgrad_partial, p.grad(n1.conv + ".weight"), p.M, p.st));
         TR_TRY(tr_colsum_add(t.g[1], t.col_partial, p.grad(n1.conv + ".bias"), p.M, p.st));
-        TR_TRY(launch_conv3x3_linear(p.S, t.g[1], t.img_d + (size_t)(l1 - 1) * img, t.zero128, t.g[2], t.g[0], p.M, p.st));
+        TR_TRY(conv_linear(p, t.g[1], t.img_d + (size_t)(l1 - 1) * img, t.zero128, t.g[2], t.g[0]));
     }
     TR_TRY(bn_layer_bwd(p, 0, t.g[0], t.x[0], t.g[1], nullptr));
     return tr_conv0_bwd(p.S, states, t.g[1], t.kind == 0 ? 0.5f : 0.0f, p.grad("main.0.weight"), p.grad("main.0.bias"), p.M, p.st);

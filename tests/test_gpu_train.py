@@ -84,8 +84,8 @@ TIGHT, LOOSE = 2e-5, 1e-2
 
 @pytest.mark.parametrize("kind,size,n,layers,seed,tight", [
     ("ac", 5, 2, 0, 0, True), ("val", 5, 3, 0, 0, True), ("ac", 5, 2, 1, 1, True), ("val", 7, 2, 1, 0, True),
-    ("ac", 5, 7, 3, 0, True), ("ac", 7, 33, 2, 0, True), ("ac", 13, 5, 1, 1, True), ("ac", 19, 4, 3, 0, True),
-    ("ac", 9, 32, 3, 1, True), ("val", 9, 64, 3, 0, False)])
+    ("ac", 5, 7, 3, 0, True), ("ac", 7, 33, 2, 0, True), ("ac", 13, 5, 1, 1, True), ("ac", 19, 4, 3, 1, True),
+    ("ac", 9, 32, 3, 0, True), ("val", 9, 64, 3, 0, False)])
 def test_train_step_matches_oracle(kind, size, n, layers, seed, tight):
     rng = np.random.default_rng(seed)
     sd = nn_ref.make_state_dict(kind, size, 11, layers=layers)

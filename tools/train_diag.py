@@ -38,7 +38,9 @@ def run(kind, size, n, layers, seed):
     c.close()
 
 
-for cfg in [("ac", 5, 2, 0), ("val", 5, 3, 0), ("ac", 5, 2, 1), ("ac", 5, 4, 1), ("val", 7, 2, 1), ("ac", 5, 7, 3), ("ac", 7, 33, 2),
-            ("val", 9, 64, 3), ("ac", 13, 5, 1), ("ac", 19, 4, 3), ("ac", 9, 32, 3)]:
-    for seed in range(4):
+cfgs = [("ac", 19, 4, 3), ("ac", 9, 32, 3), ("ac", 13, 5, 1), ("ac", 7, 33, 2)]
+if len(sys.argv) > 4:
+    cfgs = [(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))]
+for cfg in cfgs:
+    for seed in range(6):
         run(*cfg, seed)
