@@ -3,6 +3,10 @@
 //
 // Boundary format = the reference's GymGo state: uint8 planes [n][6][S][S]
 // (/root/reference/go_ai/data.py:15-24 reads plane 3 as the invalid-move mask).
+#include <cstdlib>
+#include <string>
+
+#include "go_bits.h"
 #include "go_board.h"
 #include "goai_internal.h"
 
@@ -146,13 +150,353 @@ __global__ __launch_bounds__(64) void k_liberties(const uint8_t* __restrict__ st
     }
 }
 
+// ---- one board per LANE (go_bits.h) -----------------------------------------------------------------------------------
+// A wave owns 64 consecutive work items.  The uint8 planes of the boundary are read and written by the whole wave,
+// one board at a time (ballots in, bit tests out: coalesced accesses), the rules run in the lanes' registers.
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int j)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, j);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), j);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// lane j's child position -> its six planes (or all zeros if the move was illegal)
+template <int S>
+__device__ __forceinline__ void lane_child_store(uint8_t* o, int j, const BB<S>& nme, const BB<S>& nopp, const BB<S>& ninv,
+                                                 uint32_t nflags, int rc, int player, int canonical)
+{
+    using G = Geom<S>;
+    uint64_t a[G::K], b[G::K], iv[G::K];
+#pragma unroll
+    for (int k = 0; k < G::K; k++) { a[k] = readlane64(nme.w[k], j); b[k] = readlane64(nopp.w[k], j); iv[k] = readlane64(ninv.w[k], j); }
+    const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)nflags, j);
+    const int r = __builtin_amdgcn_readlane(rc, j), np = 1 - __builtin_amdgcn_readlane(player, j);
+    if (r == 0) {
+        if (canonical || np == 0) planes_store<S>(o, a, b, iv, canonical ? 0 : np, f);
+        else planes_store<S>(o, b, a, iv, np, f);
+    } else {
+        for (int q = lane_id(); q < 6 * G::P; q += 64) o[q] = 0;
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void k_transition_lanes(const uint8_t* __restrict__ states, const int32_t* __restrict__ actions,
+                                                          int canonical, uint8_t* __restrict__ out, int32_t* __restrict__ status, int n)
+{
+    using G = Geom<S>;
+    const int lane = lane_id();
+    const long first = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (first >= n) return;
+    const int nb = (int)min((long)64, (long)n - first);
+    const int action = lane < nb ? actions[first + lane] : -1;
+    BB<S> me = bb_zero<S>(), opp = bb_zero<S>();
+    bool inv_at = false;
+    uint32_t flags = 0;
+    int player = 0;
+    for (int j = 0; j < nb; j++) {
+        uint64_t m[G::K], o[G::K], iv[G::K];
+        uint32_t f;
+        const int pl = planes_load<S>(states + (size_t)(first + j) * 6 * G::P, m, o, iv, f);
+        if (lane == j) {
+            BB<S> ivb;
+#pragma unroll
+            for (int k = 0; k < G::K; k++) { me.w[k] = m[k]; opp.w[k] = o[k]; ivb.w[k] = iv[k]; }
+            inv_at = action >= 0 && action < G::P && bb_test(ivb, action);
+            flags = f;
+            player = pl;
+        }
+    }
+    BB<S> nme = bb_zero<S>(), nopp = bb_zero<S>(), ninv = bb_zero<S>();
+    uint32_t nflags = 0;
+    int sign = 0;
+    const int rc = bits_next_state<S>(me, opp, inv_at, flags, action, nme, nopp, ninv, nflags, sign);
+    for (int j = 0; j < nb; j++)
+        lane_child_store<S>(out + (size_t)(first + j) * 6 * G::P, j, nme, nopp, ninv, nflags, rc, player, canonical);
+    if (lane < nb && status) status[first + lane] = rc;
+}
+
+// one lane per (state, action)
+template <int S>
+__global__ __launch_bounds__(256) void k_children_lanes(const uint8_t* __restrict__ states, int canonical, uint8_t* __restrict__ children,
+                                                        uint8_t* __restrict__ valid, int8_t* __restrict__ win, int n)
+{
+    using G = Geom<S>;
+    const int lane = lane_id();
+    const long total = (long)n * G::A;
+    const long first = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (first >= total) return;
+    const int nb = (int)min((long)64, total - first);
+    const long w = first + lane;
+    const int my_board = lane < nb ? (int)(w / G::A) : -1, action = lane < nb ? (int)(w % G::A) : -1;
+    BB<S> me = bb_zero<S>(), opp = bb_zero<S>();
+    bool inv_at = false;
+    uint32_t flags = 0;
+    int player = 0;
+    const int b0 = (int)(first / G::A), b1 = (int)((first + nb - 1) / G::A);
+    for (int b = b0; b <= b1; b++) {                       // the few parents this wave's items come from
+        uint64_t m[G::K], o[G::K], iv[G::K];
+        uint32_t f;
+        const int pl = planes_load<S>(states + (size_t)b * 6 * G::P, m, o, iv, f);
+        if (my_board == b) {
+            BB<S> ivb;
+#pragma unroll
+            for (int k = 0; k < G::K; k++) { me.w[k] = m[k]; opp.w[k] = o[k]; ivb.w[k] = iv[k]; }
+            inv_at = action < G::P && bb_test(ivb, action);
+            flags = f;
+            player = pl;
+        }
+    }
+    BB<S> nme = bb_zero<S>(), nopp = bb_zero<S>(), ninv = bb_zero<S>();
+    uint32_t nflags = 0;
+    int sign = 0;
+    const int rc = bits_next_state<S>(me, opp, inv_at, flags, action, nme, nopp, ninv, nflags, sign);
+    for (int j = 0; j < nb; j++)
+        lane_child_store<S>(children + (size_t)(first + j) * 6 * G::P, j, nme, nopp, ninv, nflags, rc, player, canonical);
+    if (lane < nb) {
+        if (valid) valid[w] = rc == 0;
+        if (win) {
+            const int s_abs = (canonical || player == 1) ? sign : -sign;       // as k_children
+            win[w] = (int8_t)((rc == 0 && (nflags & FLAG_DONE)) ? s_abs : 0);
+        }
+    }
+}
+
+// areas / ended / winner (score != 0) or the liberty counts of get_num_liberties (score == 0), one lane per state
+template <int S, bool SCORE>
+__global__ __launch_bounds__(256) void k_score_lanes(const uint8_t* __restrict__ states, int32_t* __restrict__ o0, int32_t* __restrict__ o1,
+                                                     int32_t* __restrict__ ended, int32_t* __restrict__ winner, int n)
+{
+    using G = Geom<S>;
+    const int lane = lane_id();
+    const long first = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (first >= n) return;
+    const int nb = (int)min((long)64, (long)n - first);
+    BB<S> me = bb_zero<S>(), opp = bb_zero<S>();
+    uint32_t flags = 0;
+    int player = 0;
+    for (int j = 0; j < nb; j++) {
+        uint64_t m[G::K], o[G::K], iv[G::K];
+        uint32_t f;
+        const int pl = planes_load<S>(states + (size_t)(first + j) * 6 * G::P, m, o, iv, f);
+        if (lane == j) {
+#pragma unroll
+            for (int k = 0; k < G::K; k++) { me.w[k] = m[k]; opp.w[k] = o[k]; }
+            flags = f;
+            player = pl;
+        }
+    }
+    if (lane >= nb) return;
+    int a_me, a_opp;
+    if (SCORE) bits_areas<S>(me, opp, a_me, a_opp);
+    else {
+        const BB<S> emp = bb_andnot(bb_board<S>(), bb_or(me, opp));
+        a_me = bb_count(bb_and(bb_nbr(me), emp));
+        a_opp = bb_count(bb_and(bb_nbr(opp), emp));
+    }
+    const int b = player ? a_opp : a_me, w = player ? a_me : a_opp;      // planes 0 / 1 as given
+    if (o0) o0[first + lane] = b;
+    if (o1) o1[first + lane] = w;
+    if (SCORE) {
+        if (ended) ended[first + lane] = (flags & FLAG_DONE) ? 1 : 0;
+        if (winner) winner[first + lane] = (b > w) - (b < w);
+    }
+}
+
+// ---- one board per lane, records staged through LDS --------------------------------------------------------------------
+// The same per-lane rules with the boundary's byte records moved as whole 16-byte lines: a wave copies the records of
+// NBL consecutive states (one contiguous, 16-byte aligned stretch of HBM) into LDS, every lane packs / unpacks its own
+// record there, and results leave the same way.  For 16-byte aligned `states` / `out` (the launchers check).
+template <int S>
+struct Staged {
+    static constexpr int REC = 6 * S * S;
+    static constexpr int NBL = S <= 9 ? 64 : (S == 13 ? 32 : 16);          // records per LDS pass (<= 35 KB)
+    static constexpr int LDS_U4 = (NBL * REC + 15) / 16;
+    static_assert((NBL * REC) % 16 == 0, "a pass is whole 16-byte units");
+};
+
+// HBM -> LDS: `bytes` bytes from src (16-byte aligned); only the last 16-byte unit of the whole array can be partial
+__device__ __forceinline__ void stage_in(uint4* lds, const uint8_t* src, long bytes)
+{
+    const int lane = lane_id();
+    for (long c = lane; c * 16 < bytes; c += 64) {
+        if ((c + 1) * 16 <= bytes) lds[c] = *reinterpret_cast<const uint4*>(src + c * 16);
+        else
+            for (long t = c * 16; t < bytes; t++) reinterpret_cast<uint8_t*>(lds)[t] = src[t];
+    }
+}
+__device__ __forceinline__ void stage_out(uint8_t* dst, const uint4* lds, long bytes)
+{
+    const int lane = lane_id();
+    for (long c = lane; c * 16 < bytes; c += 64) {
+        if ((c + 1) * 16 <= bytes) *reinterpret_cast<uint4*>(dst + c * 16) = lds[c];
+        else
+            for (long t = c * 16; t < bytes; t++) dst[t] = reinterpret_cast<const uint8_t*>(lds)[t];
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void k_transition_staged(const uint8_t* __restrict__ states, const int32_t* __restrict__ actions,
+                                                          int canonical, uint8_t* __restrict__ out, int32_t* __restrict__ status, int n)
+{
+    using T = Staged<S>;
+    __shared__ uint4 lds[T::LDS_U4];
+    uint8_t* bytes = reinterpret_cast<uint8_t*>(lds);
+    const int lane = lane_id();
+    const long first = (long)blockIdx.x * 64;
+    const int nb = (int)min((long)64, (long)n - first);
+    const int action = lane < nb ? actions[first + lane] : -1;
+    BB<S> me = bb_zero<S>(), opp = bb_zero<S>();
+    bool inv_at = false;
+    uint32_t flags = 0;
+    int player = 0;
+#pragma unroll 1
+    for (int q = 0; q * T::NBL < nb; q++) {
+        const int cnt = min(T::NBL, nb - q * T::NBL);
+        stage_in(lds, states + (size_t)(first + q * T::NBL) * T::REC, (long)cnt * T::REC);
+        __syncthreads();
+        const int l = lane - q * T::NBL;
+        if (l >= 0 && l < cnt) player = record_load<S>(bytes + l * T::REC, action, me, opp, inv_at, flags);
+        __syncthreads();
+    }
+    BB<S> nme = bb_zero<S>(), nopp = bb_zero<S>(), ninv = bb_zero<S>();
+    uint32_t nflags = 0;
+    int sign = 0;
+    const int rc = bits_next_state<S, false>(me, opp, inv_at, flags, action, nme, nopp, ninv, nflags, sign);
+    const int np = 1 - player;
+    const bool keep = canonical || np == 0;                     // the next mover's stones in plane 0
+#pragma unroll 1
+    for (int q = 0; q * T::NBL < nb; q++) {
+        const int cnt = min(T::NBL, nb - q * T::NBL);
+        const int l = lane - q * T::NBL;
+        if (l >= 0 && l < cnt) record_store<S>(bytes + l * T::REC, rc == 0, keep ? nme : nopp, keep ? nopp : nme, ninv, canonical ? 0 : np, nflags);
+        __syncthreads();
+        stage_out(out + (size_t)(first + q * T::NBL) * T::REC, lds, (long)cnt * T::REC);
+        __syncthreads();
+    }
+    if (lane < nb && status) status[first + lane] = rc;
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void k_children_staged(const uint8_t* __restrict__ states, int canonical, uint8_t* __restrict__ children,
+                                                        uint8_t* __restrict__ valid, int8_t* __restrict__ win, int n)
+{
+    using G = Geom<S>;
+    using T = Staged<S>;
+    __shared__ uint4 lds[T::LDS_U4];
+    uint8_t* bytes = reinterpret_cast<uint8_t*>(lds);
+    const int lane = lane_id();
+    const long total = (long)n * G::A;
+    const long first = (long)blockIdx.x * 64;
+    const int nb = (int)min((long)64, total - first);
+    const long w = first + lane;
+    const int my_board = lane < nb ? (int)(w / G::A) : -1, action = lane < nb ? (int)(w % G::A) : -1;
+    BB<S> me = bb_zero<S>(), opp = bb_zero<S>();
+    bool inv_at = false;
+    uint32_t flags = 0;
+    int player = 0;
+    const int b0 = (int)(first / G::A), b1 = (int)((first + nb - 1) / G::A);
+    for (int b = b0; b <= b1; b++) {                       // the few parents this wave's items come from
+        uint64_t m[G::K], o[G::K], iv[G::K];
+        uint32_t f;
+        const int pl = planes_load<S>(states + (size_t)b * 6 * G::P, m, o, iv, f);
+        if (my_board == b) {
+            BB<S> ivb;
+#pragma unroll
+            for (int k = 0; k < G::K; k++) { me.w[k] = m[k]; opp.w[k] = o[k]; ivb.w[k] = iv[k]; }
+            inv_at = action < G::P && bb_test(ivb, action);
+            flags = f;
+            player = pl;
+        }
+    }
+    BB<S> nme = bb_zero<S>(), nopp = bb_zero<S>(), ninv = bb_zero<S>();
+    uint32_t nflags = 0;
+    int sign = 0;
+    const int rc = bits_next_state<S>(me, opp, inv_at, flags, action, nme, nopp, ninv, nflags, sign);
+    const int np = 1 - player;
+    const bool keep = canonical || np == 0;
+#pragma unroll 1
+    for (int q = 0; q * T::NBL < nb; q++) {
+        const int cnt = min(T::NBL, nb - q * T::NBL);
+        const int l = lane - q * T::NBL;
+        if (l >= 0 && l < cnt) record_store<S>(bytes + l * T::REC, rc == 0, keep ? nme : nopp, keep ? nopp : nme, ninv, canonical ? 0 : np, nflags);
+        __syncthreads();
+        stage_out(children + (size_t)(first + q * T::NBL) * T::REC, lds, (long)cnt * T::REC);
+        __syncthreads();
+    }
+    if (lane < nb) {
+        if (valid) valid[w] = rc == 0;
+        if (win) {
+            const int s_abs = (canonical || player == 1) ? sign : -sign;       // as k_children
+            win[w] = (int8_t)((rc == 0 && (nflags & FLAG_DONE)) ? s_abs : 0);
+        }
+    }
+}
+
+template <int S, bool SCORE>
+__global__ __launch_bounds__(64) void k_score_staged(const uint8_t* __restrict__ states, int32_t* __restrict__ o0, int32_t* __restrict__ o1,
+                                                     int32_t* __restrict__ ended, int32_t* __restrict__ winner, int n)
+{
+    using T = Staged<S>;
+    __shared__ uint4 lds[T::LDS_U4];
+    const uint8_t* bytes = reinterpret_cast<const uint8_t*>(lds);
+    const int lane = lane_id();
+    const long first = (long)blockIdx.x * 64;
+    const int nb = (int)min((long)64, (long)n - first);
+    BB<S> me = bb_zero<S>(), opp = bb_zero<S>();
+    bool inv_at = false;
+    uint32_t flags = 0;
+    int player = 0;
+#pragma unroll 1
+    for (int q = 0; q * T::NBL < nb; q++) {
+        const int cnt = min(T::NBL, nb - q * T::NBL);
+        stage_in(lds, states + (size_t)(first + q * T::NBL) * T::REC, (long)cnt * T::REC);
+        __syncthreads();
+        const int l = lane - q * T::NBL;
+        if (l >= 0 && l < cnt) player = record_load<S>(bytes + l * T::REC, -1, me, opp, inv_at, flags);
+        __syncthreads();
+    }
+    if (lane >= nb) return;
+    int a_me, a_opp;
+    if (SCORE) bits_areas<S>(me, opp, a_me, a_opp);
+    else {
+        const BB<S> emp = bb_andnot(bb_board<S>(), bb_or(me, opp));
+        a_me = bb_count(bb_and(bb_nbr(me), emp));
+        a_opp = bb_count(bb_and(bb_nbr(opp), emp));
+    }
+    const int b = player ? a_opp : a_me, w = player ? a_me : a_opp;      // planes 0 / 1 as given
+    if (o0) o0[first + lane] = b;
+    if (o1) o1[first + lane] = w;
+    if (SCORE) {
+        if (ended) ended[first + lane] = (flags & FLAG_DONE) ? 1 : 0;
+        if (winner) winner[first + lane] = (b > w) - (b < w);
+    }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int staged_grid(long units) { return (int)((units + 63) / 64); }
+
+// GOAI_GO_KERNELS=wave (read at every call) keeps the one-board-per-wavefront kernels above for these entry points (A/B
+// timing, and the tests run all variants); the search's own transitions (k_mcts_select) always use them.
+static bool go_per_lane()
+{
+    const char* e = getenv("GOAI_GO_KERNELS");
+    return !(e && std::string(e) == "wave");
+}
+static inline int lanes_grid(long units) { return (int)((units + 255) / 256); }
+
 static inline int grid_for(long units) { return (int)(units < 65536 ? (units > 0 ? units : 1) : 65536); }
 
 int launch_transition(int S_rt, const uint8_t* states, const int32_t* actions, int canonical, uint8_t* out,
                       int32_t* status, int n, hipStream_t st)
 {
     if (n <= 0) return GOAI_OK;
-    GOAI_DISPATCH_SIZE(S_rt, k_transition<S><<<dim3(grid_for(n)), dim3(64), 0, st>>>(states, actions, canonical, out, status, n));
+    if (go_per_lane() && aligned16(states) && aligned16(out)) {
+        GOAI_DISPATCH_SIZE(S_rt, k_transition_staged<S><<<dim3(staged_grid(n)), dim3(64), 0, st>>>(states, actions, canonical, out, status, n));
+    } else if (go_per_lane()) {
+        GOAI_DISPATCH_SIZE(S_rt, k_transition_lanes<S><<<dim3(lanes_grid(n)), dim3(256), 0, st>>>(states, actions, canonical, out, status, n));
+    } else {
+        GOAI_DISPATCH_SIZE(S_rt, k_transition<S><<<dim3(grid_for(n)), dim3(64), 0, st>>>(states, actions, canonical, out, status, n));
+    }
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }
@@ -161,7 +505,13 @@ int launch_children(int S_rt, const uint8_t* states, int canonical, uint8_t* chi
                     int n, hipStream_t st)
 {
     if (n <= 0) return GOAI_OK;
-    GOAI_DISPATCH_SIZE(S_rt, k_children<S><<<dim3(grid_for((long)n * (S * S + 1))), dim3(64), 0, st>>>(states, canonical, children, valid, win, n));
+    if (go_per_lane() && aligned16(children)) {
+        GOAI_DISPATCH_SIZE(S_rt, k_children_staged<S><<<dim3(staged_grid((long)n * (S * S + 1))), dim3(64), 0, st>>>(states, canonical, children, valid, win, n));
+    } else if (go_per_lane()) {
+        GOAI_DISPATCH_SIZE(S_rt, k_children_lanes<S><<<dim3(lanes_grid((long)n * (S * S + 1))), dim3(256), 0, st>>>(states, canonical, children, valid, win, n));
+    } else {
+        GOAI_DISPATCH_SIZE(S_rt, k_children<S><<<dim3(grid_for((long)n * (S * S + 1))), dim3(64), 0, st>>>(states, canonical, children, valid, win, n));
+    }
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }
@@ -169,7 +519,15 @@ int launch_children(int S_rt, const uint8_t* states, int canonical, uint8_t* chi
 int launch_liberties(int S_rt, const uint8_t* states, int32_t* black_libs, int32_t* white_libs, int n, hipStream_t st)
 {
     if (n <= 0) return GOAI_OK;
-    GOAI_DISPATCH_SIZE(S_rt, k_liberties<S><<<dim3(grid_for(n)), dim3(64), 0, st>>>(states, black_libs, white_libs, n));
+    if (go_per_lane() && S_rt > 9) {
+        GOAI_DISPATCH_SIZE(S_rt, k_liberties<S><<<dim3(grid_for(n)), dim3(64), 0, st>>>(states, black_libs, white_libs, n));
+    } else if (go_per_lane() && aligned16(states)) {
+        GOAI_DISPATCH_SIZE(S_rt, (k_score_staged<S, false><<<dim3(staged_grid(n)), dim3(64), 0, st>>>(states, black_libs, white_libs, nullptr, nullptr, n)));
+    } else if (go_per_lane()) {
+        GOAI_DISPATCH_SIZE(S_rt, (k_score_lanes<S, false><<<dim3(lanes_grid(n)), dim3(256), 0, st>>>(states, black_libs, white_libs, nullptr, nullptr, n)));
+    } else {
+        GOAI_DISPATCH_SIZE(S_rt, k_liberties<S><<<dim3(grid_for(n)), dim3(64), 0, st>>>(states, black_libs, white_libs, n));
+    }
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }
@@ -178,7 +536,16 @@ int launch_score(int S_rt, const uint8_t* states, int32_t* black_area, int32_t* 
                  int32_t* winner, int n, hipStream_t st)
 {
     if (n <= 0) return GOAI_OK;
-    GOAI_DISPATCH_SIZE(S_rt, k_score<S><<<dim3(grid_for(n)), dim3(64), 0, st>>>(states, black_area, white_area, ended, winner, n));
+    if (go_per_lane() && S_rt > 9) {
+        // big empty regions flood slowly on 3..6-word bit boards: one board per wavefront is faster for scoring there
+        GOAI_DISPATCH_SIZE(S_rt, k_score<S><<<dim3(grid_for(n)), dim3(64), 0, st>>>(states, black_area, white_area, ended, winner, n));
+    } else if (go_per_lane() && aligned16(states)) {
+        GOAI_DISPATCH_SIZE(S_rt, (k_score_staged<S, true><<<dim3(staged_grid(n)), dim3(64), 0, st>>>(states, black_area, white_area, ended, winner, n)));
+    } else if (go_per_lane()) {
+        GOAI_DISPATCH_SIZE(S_rt, (k_score_lanes<S, true><<<dim3(lanes_grid(n)), dim3(256), 0, st>>>(states, black_area, white_area, ended, winner, n)));
+    } else {
+        GOAI_DISPATCH_SIZE(S_rt, k_score<S><<<dim3(grid_for(n)), dim3(64), 0, st>>>(states, black_area, white_area, ended, winner, n));
+    }
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }

@@ -253,7 +253,7 @@ class BatchedSelfPlay:
                     white_wins=tot["white_wins"], total_steps=tot["finished_moves"] + running_moves, **self.counters())
 
     def profile_transition(self, n_boards=65536, iters=20):
-        """Time goai_transition (k_transition: GoGame.next_state) over n_boards boards -- the games' current
+        """Time goai_transition (k_transition_staged: GoGame.next_state, one board per lane) over n_boards boards -- the games' current
         positions, repeated, each with a uniformly drawn legal non-pass move -- with HIP events on the
         launch stream.  Returns the `roofline` object of the transition side: algorithmic bytes are
         6P read + 6P written per board against the HBM peak."""
@@ -281,12 +281,13 @@ class BatchedSelfPlay:
             sec = e0.elapsed_time(e1) * 1e-3 / iters
             legal = float((status == 0).float().mean())
         nbytes = n_boards * 12 * P
-        return {"bound": "hbm", "kernel": f"k_transition<{self.size}>", "achieved": round(nbytes / sec / 1e9, 1),
+        return {"bound": "hbm", "kernel": f"k_transition_staged<{self.size}>", "achieved": round(nbytes / sec / 1e9, 1),
                 "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / sec / 8e12, 4), "traffic": None,
                 "avg_launch_us": round(sec * 1e6, 2), "launches_timed": iters, "boards_per_launch": n_boards,
                 "algorithmic_bytes_per_board": 12 * P, "boards_per_s": round(n_boards / sec, 1), "legal_fraction": round(legal, 4),
-                "note": "one board per 64-lane wavefront, board in LDS: bound by the flood fill's dependent LDS round "
-                        "trips, not by HBM (DESIGN.md section 3)"}
+                "note": "one board per lane as bit boards in registers, byte records staged through LDS in 16-byte lines; "
+                        "bound by vector-ALU issue (pack / unpack of the uint8 planes and the flood fills), not by HBM "
+                        "(DESIGN.md section 3; the one-board-per-wavefront kernel it replaces here: 0.083)"}
 
     def profile_conv(self):
         """Time every conv3x3 launch of one more move with HIP events on the launch streams."""

@@ -22,6 +22,43 @@ def ctxs():
         c.close()
 
 
+# The stateless entry points have three implementations (csrc/go_kernels.hip): one board per lane with the byte
+# records staged through LDS (the default for 16-byte aligned arrays), one board per lane with wave-wide plane
+# accesses (any alignment), one board per wavefront (GOAI_GO_KERNELS=wave; also what the search kernels use).
+IMPLS = ("staged", "lanes", "wave")
+
+
+class _impl:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        import os
+        self.old = os.environ.get("GOAI_GO_KERNELS")
+        if self.name == "wave":
+            os.environ["GOAI_GO_KERNELS"] = "wave"
+        else:
+            os.environ.pop("GOAI_GO_KERNELS", None)
+        return self
+
+    def __exit__(self, *exc):
+        import os
+        os.environ.pop("GOAI_GO_KERNELS", None)
+        if self.old is not None:
+            os.environ["GOAI_GO_KERNELS"] = self.old
+
+    def states(self, states):
+        """The states as a device tensor; for "lanes" at an address that is not 16-byte aligned."""
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(states) != 0).astype(np.uint8)).cuda()
+        if self.name != "lanes":
+            return t
+        pad = torch.zeros((1,) + tuple(t.shape[1:]), dtype=torch.uint8, device="cuda")
+        shifted = torch.cat([pad, t])[1:]
+        assert shifted.data_ptr() % 16 != 0 and shifted.is_contiguous()
+        return shifted
+
+
 def _random_actions(states, rng, illegal_frac=0.1):
     acts = []
     for st in states:
@@ -40,10 +77,12 @@ def test_transition_matches_oracle(ctxs, size, n):
     acts = _random_actions(states, rng)
     for canonical in (True, False):
         want, wstatus = GoGame.next_states_u8(states, acts, canonical=canonical)
-        got, gstatus = ctxs(size).transition(states, acts, canonical=canonical)
-        got, gstatus = got.cpu().numpy(), gstatus.cpu().numpy()
-        assert np.array_equal(gstatus != 0, wstatus != 0)
-        assert np.array_equal(got, want)
+        for name in IMPLS:
+            with _impl(name) as impl:
+                got, gstatus = ctxs(size).transition(impl.states(states), acts, canonical=canonical)
+                got, gstatus = got.cpu().numpy(), gstatus.cpu().numpy()
+            assert np.array_equal(gstatus != 0, wstatus != 0), name
+            assert np.array_equal(got, want), name
 
 
 @pytest.mark.parametrize("size,n", [(5, 64), (9, 96), (13, 16), (19, 6)])
@@ -51,6 +90,9 @@ def test_children_valid_win_match_oracle(ctxs, size, n):
     states = random_positions(size, n, seed=10 + size, max_moves=int(1.2 * size * size), canonical=True,
                               pass_prob=0.15)
     kids, valid, win = [t.cpu().numpy() for t in ctxs(size).children(states, canonical=True)]
+    with _impl("wave") as impl:                                # the one-board-per-wavefront kernel gives the same bytes
+        for a, b in zip((kids, valid, win), ctxs(size).children(impl.states(states), canonical=True)):
+            assert np.array_equal(a, b.cpu().numpy())
     for i, st in enumerate(states):
         wk, wv = GoGame.children_u8(st, canonical=True)
         assert np.array_equal(valid[i], wv)
@@ -68,6 +110,13 @@ def test_score_matches_oracle(ctxs, size, n):
         assert (b[i], w[i]) == GoGame.areas(st)
         assert ended[i] == GoGame.game_ended(st)
         assert winner[i] == GoGame.winning(st)
+    for name in ("lanes", "wave"):
+        with _impl(name) as impl:
+            for a, t in zip((b, w, ended, winner), ctxs(size).score(impl.states(states))):
+                assert np.array_equal(a, t.cpu().numpy()), name
+            lb, lw = [t.cpu().numpy() for t in ctxs(size).liberties(impl.states(states))]
+        lb0, lw0 = [t.cpu().numpy() for t in ctxs(size).liberties(states)]
+        assert np.array_equal(lb, lb0) and np.array_equal(lw, lw0), name
 
 
 def test_edge_cases(ctxs):
