@@ -110,6 +110,22 @@ __device__ __forceinline__ BB<S> bb_flood(const BB<S>& seed, const BB<S>& mask)
     }
 }
 
+// Grow g (a subset of one group of `mask`) until it is the whole group or has at least `enough` liberties; returns the
+// number of liberties found (the exact count when the group is complete), the liberties themselves in `libs`.
+template <int S>
+__device__ __forceinline__ int bb_flood_libs(BB<S>& g, const BB<S>& mask, const BB<S>& emp, int enough, BB<S>& libs)
+{
+    for (;;) {
+        const BB<S> nb = bb_nbr(g);
+        libs = bb_and(nb, emp);
+        const int c = bb_count(libs);
+        if (c >= enough) return c;
+        const BB<S> n = bb_or(g, bb_and(nb, mask));
+        if (bb_eq(n, g)) return c;
+        g = n;
+    }
+}
+
 // areas of a position as given (planes 0 / 1 = a / b): stones plus empty regions touching one colour only
 template <int S>
 __device__ __forceinline__ void bits_areas(const BB<S>& a, const BB<S>& b, int& area_a, int& area_b)
@@ -153,9 +169,10 @@ __device__ __forceinline__ int bits_next_state(const BB<S>& me, const BB<S>& opp
         BB<S> cand = bb_and(around, o), cap = bb_zero<S>();
         int ncap = 0;
         while (bb_any(cand)) {
-            const BB<S> g = bb_flood(bb_lowest(cand), o);
+            BB<S> g = bb_lowest(cand), libs;
+            const int c = bb_flood_libs(g, o, emp, 1, libs);        // stops at the first liberty (the group may be partial then)
             cand = bb_andnot(cand, g);
-            if (!bb_any(bb_and(bb_nbr(g), emp))) { cap = bb_or(cap, g); ncap++; }
+            if (c == 0) { cap = bb_or(cap, g); ncap++; }
         }
         o = bb_andnot(o, cap);
         if (ncap == 1 && bb_count(cap) == 1 && surrounded) ko = cap;   // one stone taken by a stone that was surrounded: ko
@@ -169,18 +186,20 @@ __device__ __forceinline__ int bits_next_state(const BB<S>& me, const BB<S>& opp
     if (bb_any(need)) {
         const BB<S> near = bb_nbr(need);
         BB<S> cand = bb_and(near, o);
+        // (a flood stops as soon as two liberties are known; stones of the same group that it has not reached stay in
+        // `cand` and start a flood of their own, so every point next to the group is still seen)
         while (bb_any(cand)) {
-            const BB<S> g = bb_flood(bb_lowest(cand), o);
+            BB<S> g = bb_lowest(cand), libs;
+            const int c = bb_flood_libs(g, o, emp, 2, libs);
             cand = bb_andnot(cand, g);
-            const BB<S> libs = bb_and(bb_nbr(g), emp);
-            if (bb_count(libs) >= 2) valid = bb_or(valid, libs);
+            if (c >= 2) valid = bb_or(valid, libs);
         }
         cand = bb_and(near, m);
         while (bb_any(cand)) {
-            const BB<S> g = bb_flood(bb_lowest(cand), m);
+            BB<S> g = bb_lowest(cand), libs;
+            const int c = bb_flood_libs(g, m, emp, 2, libs);
             cand = bb_andnot(cand, g);
-            const BB<S> libs = bb_and(bb_nbr(g), emp);
-            if (bb_count(libs) == 1) valid = bb_or(valid, libs);
+            if (c == 1) valid = bb_or(valid, libs);
         }
     }
     ninv = bb_or(bb_andnot(bb_board<S>(), valid), ko);
