@@ -42,11 +42,13 @@ for path in glob.glob(os.path.join(out, "go_kernel_stats.csv")):
             stats[short(row["Name"])] = dict(calls=int(row["Calls"]), avg_us=float(row["AverageNs"]) / 1e3)
 fetch, write = load("go_fetch"), load("go_write")
 N = 65536
-ALGO = {   # algorithmic bytes per launch: planes at one byte per cell
-    "k_transition<9>": N * 12 * 81, "k_transition<19>": N * 12 * 361,
-    "k_score<9>": N * 6 * 81, "k_score<19>": N * 6 * 361,
-    "k_children<9>": (N // 64) * 83 * 6 * 81, "k_children<19>": (N // 64) * 363 * 6 * 361,
-}
+ALGO = {}  # algorithmic bytes per launch: planes at one byte per cell
+for variant in ("", "_staged", "_lanes"):
+    for S in (9, 19):
+        P = S * S
+        ALGO[f"k_transition{variant}<{S}>"] = N * 12 * P
+        ALGO[f"k_score{variant}<{S}>"] = ALGO[f"k_score{variant}<{S}, true>"] = N * 6 * P
+        ALGO[f"k_children{variant}<{S}>"] = (N // 64) * (P + 2) * 6 * P
 rows = []
 for k in sorted(set(fetch) | set(write)):
     if not (k.startswith("k_transition") or k.startswith("k_score") or k.startswith("k_children")):
