@@ -224,16 +224,16 @@ def gloo_rehearsal(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: about 5 s of GPU time for the config)")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed steps before them (default: 5 for c2, else 1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--games", type=int, default=0, help="games per GPU (default: the config's)")
     ap.add_argument("--dtype", choices=["auto", "f32", "bf16x3", "bf16x6"], default="auto",
-                    help="arithmetic of the trunk convolutions.  auto = bf16x6 on 9x9 boards (bf16 matrix cores on operands "
-                         "split exactly into three bf16 parts: fp32-grade results, error at the exact-fp32 Winograd kernel's own "
-                         "level), f32 elsewhere; f32 = exact fp32 MFMA everywhere; bf16x3 = two-part split (1e-5 class, opt-in)")
+                    help="arithmetic of the trunk convolutions.  auto = bf16x6 (bf16 matrix cores on operands split exactly "
+                         "into three bf16 parts: fp32-grade results, error at the exact-fp32 Winograd kernels' own level); "
+                         "f32 = exact fp32 MFMA everywhere; bf16x3 = two-part split (1e-5 class, opt-in)")
     ap.add_argument("--groups", type=int, default=1, help="independent game groups on separate HIP streams")
     ap.add_argument("--no-refill", action="store_true",
                     help="leave the slot of a finished game idle instead of starting the next game in it")
@@ -244,6 +244,11 @@ def main():
                     help="gloo: CPU rehearsal of the N-rank launch / rendezvous / gather path with a stub body (no GPU)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    # defaults sized so that the timed region is seconds, not a blink (a step of c2 is 42 ms, of c5 2.8 s)
+    if args.steps <= 0:
+        args.steps = {"c2": 120, "c3": 6, "c4": 6, "c5": 3}.get(args.config, 8)
+    if args.warmup < 0:
+        args.warmup = 5 if args.config == "c2" else 1
     if args.dtype == "auto":
         args.dtype = "bf16x6"
     global SIZE, SIMS, LAYERS
