@@ -351,9 +351,10 @@ def main():
     achieved = executed_flop / launch_s / 1e12           # TFLOP/s the matrix pipe sustains
     effective = conv_flop / launch_s / 1e12              # the convolution's own flops per second (Winograd executes fewer)
 
-    # the transition side (north_star subsystem 1): k_transition over 65,536 boards taken from the games'
+    # the transition side (north_star subsystem 1): k_transition over 262,144 boards (the size of one Q-search
+    # make_children step of 4096 games) taken from the games'
     # current positions, HIP events on the launch stream; algorithmic bytes = 6P in + 6P out per board
-    tr = sp.profile_transition(65536)
+    tr = sp.profile_transition(262144)
 
     # the one collective of the run: gather per-rank results (utils.py:201-204's allreduces)
     from go_ai.sharding import gather_stats, reduce_stats

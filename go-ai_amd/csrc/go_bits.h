@@ -215,29 +215,55 @@ __device__ __forceinline__ int bits_next_state(const BB<S>& me, const BB<S>& opp
 }
 
 // ---- the boundary's uint8 records ([6][P] bytes per state) in LDS, one record per lane -----------------------------------
+// A record sits at an arbitrary (even) LDS address and its planes at odd offsets: everything below moves four cells per
+// LDS access through unaligned ds_read_b32 / ds_write_b32 (gfx950 takes them at any alignment; memcpy lets the compiler
+// choose).  P = 1 (mod 4) for every board size, so a plane is (P - 1) / 4 whole words and one last byte.
+__device__ __forceinline__ uint32_t lds_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ void lds_put_u32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+// bit 7 of every byte of x that is not zero
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) { return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; }
+// the four flags (bit 7 of each byte) as bits 0..3
+__device__ __forceinline__ uint32_t gather4(uint32_t f)
+{
+    const uint32_t x = f >> 7;                   // flags at bits 0, 8, 16, 24
+    const uint32_t t = x | (x >> 7);             // bits 0, 1 and 16, 17
+    return (t | (t >> 14)) & 0xfu;
+}
+// four cells (bits 0..3 of n) as four bytes of 0 / 1
+__device__ __forceinline__ uint32_t spread4(uint32_t n) { return __umul24(n & 0xfu, 0x204081u) & 0x01010101u; }
+
 // planes 0 / 1 as bit boards, any(turn plane), any(pass plane), all(done plane) -- GymGo's turn / prev_player_passed /
 // game_ended -- and the invalid-plane byte at `action`
 template <int S>
 __device__ __forceinline__ int record_load(const uint8_t* rec, int action, BB<S>& me, BB<S>& opp, bool& inv_at, uint32_t& flags)
 {
-    constexpr int P = BitGeom<S>::P, NW = BitGeom<S>::NW;
+    constexpr int P = BitGeom<S>::P, NW = BitGeom<S>::NW, ND = P / 4;      // whole words per plane; byte P - 1 is left over
+    static_assert(P % 4 == 1, "odd board sizes");
     uint32_t c0[2 * NW], c1[2 * NW];
 #pragma unroll
     for (int h = 0; h < 2 * NW; h++) { c0[h] = 0; c1[h] = 0; }
-    uint32_t any_turn = 0, any_pass = 0, n_done = 0;
+    uint32_t any_turn = 0, any_pass = 0, all_done = 0x80808080u;
 #pragma unroll
     for (int h = 0; h < 2 * NW; h++) {
-#pragma unroll 8
-        for (int b = 0; b < 32; b++) {
-            const int i = h * 32 + b;
-            if (i < P) {
-                c0[h] |= min((uint32_t)rec[i], 1u) << b;
-                c1[h] |= min((uint32_t)rec[P + i], 1u) << b;
-                any_turn |= rec[2 * P + i];
-                any_pass |= rec[4 * P + i];
-                n_done += min((uint32_t)rec[5 * P + i], 1u);
+#pragma unroll
+        for (int n = 0; n < 8; n++) {                            // cells 32 h + 4 n .. + 3 -> bits 4 n .. of word h
+            const int j = 8 * h + n;
+            if (j < ND) {
+                c0[h] |= gather4(nonzero_bytes(lds_u32(rec + 4 * j))) << (4 * n);
+                c1[h] |= gather4(nonzero_bytes(lds_u32(rec + P + 4 * j))) << (4 * n);
+                any_turn |= lds_u32(rec + 2 * P + 4 * j);
+                any_pass |= lds_u32(rec + 4 * P + 4 * j);
+                all_done &= nonzero_bytes(lds_u32(rec + 5 * P + 4 * j));
             }
         }
+    }
+    {   // the last cell of every plane
+        constexpr int i = P - 1;
+        c0[i >> 5] |= (rec[i] != 0 ? 1u : 0u) << (i & 31);
+        c1[i >> 5] |= (rec[P + i] != 0 ? 1u : 0u) << (i & 31);
+        any_turn |= rec[2 * P + i];
+        any_pass |= rec[4 * P + i];
+        if (rec[5 * P + i] == 0) all_done = 0;
     }
     const int player = any_turn ? 1 : 0;
 #pragma unroll
@@ -247,7 +273,7 @@ __device__ __forceinline__ int record_load(const uint8_t* rec, int action, BB<S>
         opp.w[k] = player ? a : b;
     }
     inv_at = action >= 0 && action < P && rec[3 * P + action] != 0;
-    flags = (any_pass ? FLAG_PASS : 0u) | (n_done == (uint32_t)P ? FLAG_DONE : 0u);
+    flags = (any_pass ? FLAG_PASS : 0u) | (all_done == 0x80808080u ? FLAG_DONE : 0u);
     return player;
 }
 
@@ -256,25 +282,38 @@ template <int S>
 __device__ __forceinline__ void record_store(uint8_t* rec, bool legal, const BB<S>& ch0, const BB<S>& ch1, const BB<S>& inv, int turn,
                                              uint32_t flags)
 {
-    constexpr int P = BitGeom<S>::P, NW = BitGeom<S>::NW;
-    const uint8_t t = legal ? (uint8_t)turn : 0, ps = (legal && (flags & FLAG_PASS)) ? 1 : 0, dn = (legal && (flags & FLAG_DONE)) ? 1 : 0;
+    constexpr int P = BitGeom<S>::P, NW = BitGeom<S>::NW, ND = P / 4;
+    const uint32_t t = (legal && turn) ? 0x01010101u : 0u, ps = (legal && (flags & FLAG_PASS)) ? 0x01010101u : 0u,
+                   dn = (legal && (flags & FLAG_DONE)) ? 0x01010101u : 0u;
+    uint32_t a[2 * NW], b[2 * NW], v[2 * NW];
 #pragma unroll
     for (int h = 0; h < 2 * NW; h++) {
-        const uint32_t a = legal ? (uint32_t)(ch0.w[h >> 1] >> (32 * (h & 1))) : 0u, b = legal ? (uint32_t)(ch1.w[h >> 1] >> (32 * (h & 1))) : 0u,
-                       v = legal ? (uint32_t)(inv.w[h >> 1] >> (32 * (h & 1))) : 0u;
-#pragma unroll 8
-        for (int bit = 0; bit < 32; bit++) {
-            const int i = h * 32 + bit;
-            if (i < P) {
-                rec[i] = (uint8_t)((a >> bit) & 1u);
-                rec[P + i] = (uint8_t)((b >> bit) & 1u);
-                rec[2 * P + i] = t;
-                rec[3 * P + i] = (uint8_t)((v >> bit) & 1u);
-                rec[4 * P + i] = ps;
-                rec[5 * P + i] = dn;
+        a[h] = legal ? (uint32_t)(ch0.w[h >> 1] >> (32 * (h & 1))) : 0u;
+        b[h] = legal ? (uint32_t)(ch1.w[h >> 1] >> (32 * (h & 1))) : 0u;
+        v[h] = legal ? (uint32_t)(inv.w[h >> 1] >> (32 * (h & 1))) : 0u;
+    }
+#pragma unroll
+    for (int h = 0; h < 2 * NW; h++) {
+#pragma unroll
+        for (int n = 0; n < 8; n++) {
+            const int j = 8 * h + n;
+            if (j < ND) {
+                lds_put_u32(rec + 4 * j, spread4(a[h] >> (4 * n)));
+                lds_put_u32(rec + P + 4 * j, spread4(b[h] >> (4 * n)));
+                lds_put_u32(rec + 2 * P + 4 * j, t);
+                lds_put_u32(rec + 3 * P + 4 * j, spread4(v[h] >> (4 * n)));
+                lds_put_u32(rec + 4 * P + 4 * j, ps);
+                lds_put_u32(rec + 5 * P + 4 * j, dn);
             }
         }
     }
+    constexpr int i = P - 1;
+    rec[i] = (uint8_t)((a[i >> 5] >> (i & 31)) & 1u);
+    rec[P + i] = (uint8_t)((b[i >> 5] >> (i & 31)) & 1u);
+    rec[2 * P + i] = (uint8_t)(t & 1u);
+    rec[3 * P + i] = (uint8_t)((v[i >> 5] >> (i & 31)) & 1u);
+    rec[4 * P + i] = (uint8_t)(ps & 1u);
+    rec[5 * P + i] = (uint8_t)(dn & 1u);
 }
 
 }  // namespace goai

@@ -306,11 +306,15 @@ __global__ __launch_bounds__(256) void k_score_lanes(const uint8_t* __restrict__
 // The same per-lane rules with the boundary's byte records moved as whole 16-byte lines: a wave copies the records of
 // NBL consecutive states (one contiguous, 16-byte aligned stretch of HBM) into LDS, every lane packs / unpacks its own
 // record there, and results leave the same way.  For 16-byte aligned `states` / `out` (the launchers check).
-template <int S>
+// NBL = records per LDS pass.  A pass costs every lane of the wave the pack / unpack instructions of one record, whichever
+// lanes own a record of it, so few large passes are cheapest per wave; but LDS per wave bounds the waves per CU, and a
+// lone wave per SIMD spends most of its time waiting for its own instructions.  The launchers take large passes for small
+// launches (every wave gets a SIMD to itself anyway) and small ones when there are waves enough to fill the SIMDs.
+template <int S, int NBL_>
 struct Staged {
     static constexpr int REC = 6 * S * S;
-    static constexpr int NBL = S <= 9 ? 64 : (S == 13 ? 32 : 16);          // records per LDS pass (<= 35 KB)
-    static constexpr int LDS_U4 = (NBL * REC + 15) / 16;
+    static constexpr int NBL = NBL_;
+    static constexpr int LDS_U4 = (NBL * REC + 15) / 16 + 1;               // + 16 bytes: the last record's last word reads 3 bytes on
     static_assert((NBL * REC) % 16 == 0, "a pass is whole 16-byte units");
 };
 
@@ -334,11 +338,11 @@ __device__ __forceinline__ void stage_out(uint8_t* dst, const uint4* lds, long b
     }
 }
 
-template <int S>
+template <int S, int NBL>
 __global__ __launch_bounds__(64) void k_transition_staged(const uint8_t* __restrict__ states, const int32_t* __restrict__ actions,
                                                           int canonical, uint8_t* __restrict__ out, int32_t* __restrict__ status, int n)
 {
-    using T = Staged<S>;
+    using T = Staged<S, NBL>;
     __shared__ uint4 lds[T::LDS_U4];
     uint8_t* bytes = reinterpret_cast<uint8_t*>(lds);
     const int lane = lane_id();
@@ -376,12 +380,12 @@ __global__ __launch_bounds__(64) void k_transition_staged(const uint8_t* __restr
     if (lane < nb && status) status[first + lane] = rc;
 }
 
-template <int S>
+template <int S, int NBL>
 __global__ __launch_bounds__(64) void k_children_staged(const uint8_t* __restrict__ states, int canonical, uint8_t* __restrict__ children,
                                                         uint8_t* __restrict__ valid, int8_t* __restrict__ win, int n)
 {
     using G = Geom<S>;
-    using T = Staged<S>;
+    using T = Staged<S, NBL>;
     __shared__ uint4 lds[T::LDS_U4];
     uint8_t* bytes = reinterpret_cast<uint8_t*>(lds);
     const int lane = lane_id();
@@ -432,11 +436,12 @@ __global__ __launch_bounds__(64) void k_children_staged(const uint8_t* __restric
     }
 }
 
-template <int S, bool SCORE>
+// SCORE != 0: areas / ended / winner; SCORE == 0: the liberty counts of get_num_liberties
+template <int S, int NBL>
 __global__ __launch_bounds__(64) void k_score_staged(const uint8_t* __restrict__ states, int32_t* __restrict__ o0, int32_t* __restrict__ o1,
-                                                     int32_t* __restrict__ ended, int32_t* __restrict__ winner, int n)
+                                                     int32_t* __restrict__ ended, int32_t* __restrict__ winner, int n, int SCORE)
 {
-    using T = Staged<S>;
+    using T = Staged<S, NBL>;
     __shared__ uint4 lds[T::LDS_U4];
     const uint8_t* bytes = reinterpret_cast<const uint8_t*>(lds);
     const int lane = lane_id();
@@ -474,6 +479,22 @@ __global__ __launch_bounds__(64) void k_score_staged(const uint8_t* __restrict__
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int staged_grid(long units) { return (int)((units + 63) / 64); }
+// records per LDS pass for a launch of `waves` waves: 0 = the largest (64 up to 9x9, 32 at 13x13, 16 at 19x19), 1 = 16 (8 at
+// 19x19).  GOAI_GO_NBL=0/1 forces one (tuning aid).
+static int staged_small_passes(int S, long waves)
+{
+    if (const char* e = getenv("GOAI_GO_NBL")) return atoi(e) != 0;
+    return S <= 13 && waves >= 1280;      // measured: the small passes win from ~1.25 waves per SIMD on (profiles/r02_go_passes.txt)
+}
+#define GOAI_STAGED_LAUNCH(S_RT, SMALL, KERNEL, ...)                                                        \
+    switch (S_RT) {                                                                                         \
+        case 5: if (SMALL) KERNEL<5, 16> __VA_ARGS__; else KERNEL<5, 64> __VA_ARGS__; break;                  \
+        case 7: if (SMALL) KERNEL<7, 16> __VA_ARGS__; else KERNEL<7, 64> __VA_ARGS__; break;                  \
+        case 9: if (SMALL) KERNEL<9, 16> __VA_ARGS__; else KERNEL<9, 64> __VA_ARGS__; break;                  \
+        case 13: if (SMALL) KERNEL<13, 16> __VA_ARGS__; else KERNEL<13, 32> __VA_ARGS__; break;               \
+        case 19: if (SMALL) KERNEL<19, 8> __VA_ARGS__; else KERNEL<19, 16> __VA_ARGS__; break;                \
+        default: set_error("unsupported board size"); return GOAI_ERR_ARG;                                  \
+    }
 
 // GOAI_GO_KERNELS=wave (read at every call) keeps the one-board-per-wavefront kernels above for these entry points (A/B
 // timing, and the tests run all variants); the search's own transitions (k_mcts_select) always use them.
@@ -491,7 +512,8 @@ int launch_transition(int S_rt, const uint8_t* states, const int32_t* actions, i
 {
     if (n <= 0) return GOAI_OK;
     if (go_per_lane() && aligned16(states) && aligned16(out)) {
-        GOAI_DISPATCH_SIZE(S_rt, k_transition_staged<S><<<dim3(staged_grid(n)), dim3(64), 0, st>>>(states, actions, canonical, out, status, n));
+        const bool small = staged_small_passes(S_rt, staged_grid(n));
+        GOAI_STAGED_LAUNCH(S_rt, small, k_transition_staged, <<<dim3(staged_grid(n)), dim3(64), 0, st>>>(states, actions, canonical, out, status, n));
     } else if (go_per_lane()) {
         GOAI_DISPATCH_SIZE(S_rt, k_transition_lanes<S><<<dim3(lanes_grid(n)), dim3(256), 0, st>>>(states, actions, canonical, out, status, n));
     } else {
@@ -506,7 +528,9 @@ int launch_children(int S_rt, const uint8_t* states, int canonical, uint8_t* chi
 {
     if (n <= 0) return GOAI_OK;
     if (go_per_lane() && aligned16(children)) {
-        GOAI_DISPATCH_SIZE(S_rt, k_children_staged<S><<<dim3(staged_grid((long)n * (S * S + 1))), dim3(64), 0, st>>>(states, canonical, children, valid, win, n));
+        const long items = (long)n * (S_rt * S_rt + 1);
+        const bool small = staged_small_passes(S_rt, staged_grid(items));
+        GOAI_STAGED_LAUNCH(S_rt, small, k_children_staged, <<<dim3(staged_grid(items)), dim3(64), 0, st>>>(states, canonical, children, valid, win, n));
     } else if (go_per_lane()) {
         GOAI_DISPATCH_SIZE(S_rt, k_children_lanes<S><<<dim3(lanes_grid((long)n * (S * S + 1))), dim3(256), 0, st>>>(states, canonical, children, valid, win, n));
     } else {
@@ -522,7 +546,8 @@ int launch_liberties(int S_rt, const uint8_t* states, int32_t* black_libs, int32
     if (go_per_lane() && S_rt > 9) {
         GOAI_DISPATCH_SIZE(S_rt, k_liberties<S><<<dim3(grid_for(n)), dim3(64), 0, st>>>(states, black_libs, white_libs, n));
     } else if (go_per_lane() && aligned16(states)) {
-        GOAI_DISPATCH_SIZE(S_rt, (k_score_staged<S, false><<<dim3(staged_grid(n)), dim3(64), 0, st>>>(states, black_libs, white_libs, nullptr, nullptr, n)));
+        const bool small = staged_small_passes(S_rt, staged_grid(n));
+        GOAI_STAGED_LAUNCH(S_rt, small, k_score_staged, <<<dim3(staged_grid(n)), dim3(64), 0, st>>>(states, black_libs, white_libs, nullptr, nullptr, n, 0));
     } else if (go_per_lane()) {
         GOAI_DISPATCH_SIZE(S_rt, (k_score_lanes<S, false><<<dim3(lanes_grid(n)), dim3(256), 0, st>>>(states, black_libs, white_libs, nullptr, nullptr, n)));
     } else {
@@ -540,7 +565,8 @@ int launch_score(int S_rt, const uint8_t* states, int32_t* black_area, int32_t* 
         // big empty regions flood slowly on 3..6-word bit boards: one board per wavefront is faster for scoring there
         GOAI_DISPATCH_SIZE(S_rt, k_score<S><<<dim3(grid_for(n)), dim3(64), 0, st>>>(states, black_area, white_area, ended, winner, n));
     } else if (go_per_lane() && aligned16(states)) {
-        GOAI_DISPATCH_SIZE(S_rt, (k_score_staged<S, true><<<dim3(staged_grid(n)), dim3(64), 0, st>>>(states, black_area, white_area, ended, winner, n)));
+        const bool small = staged_small_passes(S_rt, staged_grid(n));
+        GOAI_STAGED_LAUNCH(S_rt, small, k_score_staged, <<<dim3(staged_grid(n)), dim3(64), 0, st>>>(states, black_area, white_area, ended, winner, n, 1));
     } else if (go_per_lane()) {
         GOAI_DISPATCH_SIZE(S_rt, (k_score_lanes<S, true><<<dim3(lanes_grid(n)), dim3(256), 0, st>>>(states, black_area, white_area, ended, winner, n)));
     } else {

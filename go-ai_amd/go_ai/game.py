@@ -252,7 +252,7 @@ class BatchedSelfPlay:
         return dict(games=self.n_games, finished=tot["finished"], black_wins=tot["black_wins"],
                     white_wins=tot["white_wins"], total_steps=tot["finished_moves"] + running_moves, **self.counters())
 
-    def profile_transition(self, n_boards=65536, iters=20):
+    def profile_transition(self, n_boards=262144, iters=20):
         """Time goai_transition (k_transition_staged: GoGame.next_state, one board per lane) over n_boards boards -- the games' current
         positions, repeated, each with a uniformly drawn legal non-pass move -- with HIP events on the
         launch stream.  Returns the `roofline` object of the transition side: algorithmic bytes are
@@ -287,7 +287,7 @@ class BatchedSelfPlay:
                 "algorithmic_bytes_per_board": 12 * P, "boards_per_s": round(n_boards / sec, 1), "legal_fraction": round(legal, 4),
                 "note": "one board per lane as bit boards in registers, byte records staged through LDS in 16-byte lines; "
                         "bound by vector-ALU issue (pack / unpack of the uint8 planes and the flood fills), not by HBM "
-                        "(DESIGN.md section 3; the one-board-per-wavefront kernel it replaces here: 0.083)"}
+                        "(DESIGN.md section 3; the one-board-per-wavefront kernel it replaces here: 0.083 at 65,536 boards)"}
 
     def profile_conv(self):
         """Time every conv3x3 launch of one more move with HIP events on the launch streams."""
