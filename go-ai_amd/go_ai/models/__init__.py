@@ -153,6 +153,14 @@ class RLNet:
         self._pull_trained()
         return self
 
+    def parameters(self):
+        """The trainable tensors in the reference's parameters() order (weights and biases, not BatchNorm statistics):
+        what train.py hands to the optimiser (train.py:52) and utils.count_parameters sums.  Host copies."""
+        self._pull_trained()
+        for k, v in self._sd.items():
+            if not k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+                yield v.clone().requires_grad_(True)
+
     # -- optimisation (models/__init__.py:115-231, ac_net.py:67-86, val_net.py:29-43) -----
     def train(self):
         """Training state on the GPU (goai_train_init): raw parameters, gradients, Adam moments, BatchNorm statistics."""

@@ -226,7 +226,8 @@ def test_optimize_on_self_play_replay():
             sd = nn_ref.make_state_dict(kind, size, 6)
             net.load_state_dict(sd)
             before = net.create_numpy("critic")(cols[0][:8])
-            opt = Adam(lr=1e-3)
+            opt = Adam(net.parameters(), 1e-3, weight_decay=1e-4)                 # as train.py:52 builds torch.optim.Adam
+            assert sum(p.numel() for p in net.parameters() if p.requires_grad) == sum(sd[k].numel() for k in nn_train_ref.param_keys(sd))
             m = net.optimize(data.SoloComm(), batches, opt)
             assert isinstance(m, ModelMetrics) and np.isfinite(m.crit_loss) and 0 <= m.crit_acc <= 1
             assert (kind == "ac") == bool(ModelMetrics._has(m.act_loss))
