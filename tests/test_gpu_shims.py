@@ -488,3 +488,39 @@ def test_batched_play_against_random_and_greedy():
                 env = GoEnv(size)
                 env.state = traj.states[i].copy()      # canonical: the mover is "black"
                 assert np.allclose(greedy(env), traj.pis[i], rtol=1e-12, atol=0)
+
+
+def test_mpi_play_and_count_parameters():
+    """go_ai.utils.mpi_play (/root/reference/go_ai/utils.py:179-208) = this rank's share as one BatchedPlay run + the sums
+    over the ranks; with one rank it is BatchedPlay itself."""
+    import types
+    from go_ai import data, utils
+    from go_ai.env import GoEnv
+    from go_ai.game import BatchedPlay
+    from go_ai.models.ac_net import ActorCriticNet
+    from go_ai.policies.actorcritic import ActorCritic
+    from go_ai.policies.baselines import Random
+    size = 5
+    net = ActorCriticNet(size, max_batch=64)
+    net.load_state_dict(nn_ref.make_state_dict("ac", size, 3))
+    assert utils.count_parameters(net) == sum(v.numel() for k, v in net.state_dict().items() if not k.endswith(("running_mean", "running_var")))
+    first, second = ActorCritic("a", net, types.SimpleNamespace(temp=1, mcts=4)), Random()
+    wr, bwr, replay = utils.mpi_play(data.SoloComm(), GoEnv(size), first, second, 6, slots=4, seed=5)
+    bp = BatchedPlay(size, first, second, slots=4, seed=5)
+    bp.record()
+    fw, bw, want_replay, steps = bp.play(6)
+    assert (wr, bwr) == (fw, bw) and len(replay) == 6
+    assert all(np.array_equal(a.actions, b.actions) for a, b in zip(replay, want_replay))
+
+    class TwoRanks(data.SoloComm):              # rank 1 of 2: its three episodes are keyed 4, 5, 6 -- a different stream
+        def Get_rank(self):
+            return 1
+
+        def Get_size(self):
+            return 2
+
+        def allreduce(self, x):
+            return 2 * x
+    wr2, _, replay2 = utils.mpi_play(TwoRanks(), GoEnv(size), first, second, 6, slots=4, seed=5, device=0)
+    assert len(replay2) == 3 and 0 <= wr2 <= 1
+    assert any(not np.array_equal(a.actions, b.actions) for a, b in zip(replay2, want_replay))
