@@ -2,6 +2,7 @@
 // every step is  select (all games) -> CNN forward over the leaf batch -> expand + backup.
 // (/root/reference/go_ai/search/mct.py:50-62 runs the same three phases one leaf at a time.)
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "ctx.h"
@@ -197,6 +198,31 @@ int mcts_steps(goai_ctx* c, int n_steps)
         return GOAI_OK;
     }
     GOAI_REQUIRE(c->net.loaded && c->net.kind == 0, "an actor-critic network with loaded weights is required");
+    // The lock-step loop with everything between two trunk launches in ONE launch (k_post_forward: heads, backup, the
+    // next step's select, first convolution -- the same device code as the separate kernels, same bits).  Needs the whole
+    // batch in one forward and the matrix-core first convolution; GOAI_NO_STEP_FUSION=1 keeps the separate launches.
+    const char* nf = getenv("GOAI_NO_STEP_FUSION");          // read at every call: the tests run both paths in one process
+    const bool no_fusion = nf && nf[0] == '1';
+    // Only while all of its workgroups (two games each, three per CU) are resident at once: then the separate kernels are
+    // latency-bound chains and fusing them saves their hand-overs (C2, 1024 games: +1.2 %); with more games than that the
+    // separate kernels fill the chip better than a workgroup that is half idle in its middle phase (C4 / C5: -2 %).
+    const bool small_batch = t.n_active <= 6 * c->net.n_cu;
+    if (!no_fusion && small_batch && n_steps >= 2 && !t.pending_select && t.n_active <= c->net.max_batch && c->net.w0_split) {
+        float* x = nullptr;
+        if ((rc = mcts_select(c, nullptr))) return rc;
+        if ((rc = nn_piece_conv0(c, t.leaf_planes, t.n_active))) return rc;
+        for (int s = 0; s < n_steps; s++) {
+            if ((rc = nn_piece_trunk(c, t.n_active, &x))) return rc;
+            if (s + 1 < n_steps) {
+                if ((rc = launch_post_forward(c->S, t, x, c->net.hw, c->net.w0_split, c->net.b0, c->net.shift, c->net.act[0],
+                                              c->stream)))
+                    return rc;
+                t.steps_since_reset++;          // that step's backup and the next step's select are in the stream
+            }
+        }
+        if ((rc = nn_piece_heads(c, x, t.pi_logits, t.val_logits, t.n_active))) return rc;
+        return mcts_backup(c, t.pi_logits, nullptr, t.val_logits, 1);
+    }
     for (int s = 0; s < n_steps; s++) {
         if ((rc = mcts_select(c, nullptr))) return rc;
         if ((rc = nn_forward_raw(c, t.leaf_planes, t.pi_logits, t.val_logits, t.n_active))) return rc;

@@ -9,11 +9,32 @@
 //   mct_step         /root/reference/go_ai/search/mct.py:20-47     prior = softmax(pi_logits)
 //   ActorCritic.__call__  /root/reference/go_ai/policies/actorcritic.py:29-42  visit counts -> pi
 #include "detmath.h"
+#include "go_bits.h"
 #include "go_board.h"
 #include "goai_internal.h"
 #include "mcts.h"
+#include "nn_groups.h"
 
 namespace goai {
+// board_next_state (go_board.h) on the packed words themselves: the bit-board rules of go_bits.h with wave-uniform
+// operands (no LDS, no barriers).  Same results bit for bit (tests/test_gpu_go.py, tests/test_gpu_mcts.py).
+template <int S>
+__device__ __forceinline__ int uniform_next_state(const uint64_t* me, const uint64_t* opp, const uint64_t* inv, uint32_t flags, int action,
+                                                  uint64_t* nme, uint64_t* nopp, uint64_t* ninv, uint32_t& nflags, int& sign_out)
+{
+    using G = Geom<S>;
+    BB<S> m, o, iv, a, b, c;
+#pragma unroll
+    for (int k = 0; k < G::K; k++) { m.w[k] = me[k]; o.w[k] = opp[k]; iv.w[k] = inv[k]; }
+    const bool inv_at = action >= 0 && action < G::P && bb_test(iv, action);
+    const int rc = bits_next_state<S, true>(m, o, inv_at, flags, action, a, b, c, nflags, sign_out);
+    if (rc == 0) {
+#pragma unroll
+        for (int k = 0; k < G::K; k++) { nme[k] = a.w[k]; nopp[k] = b.w[k]; ninv[k] = c.w[k]; }
+    }
+    return rc;
+}
+
 
 template <int S>
 __device__ __forceinline__ void node_load(const Tree& t, size_t node, uint64_t* me, uint64_t* opp, uint64_t* inv,
@@ -76,14 +97,14 @@ __global__ __launch_bounds__(64) void k_mcts_reset(Tree t, const uint8_t* __rest
 // count (= the child's N), cQ, child index (-2 marks an invalid move) and the child's own row
 // (crow, -1 while the child is unvisited or terminal) -- so a level costs ONE round of
 // independent loads, not a chain of node -> visits -> row look-ups.
-template <int S>
-__global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict__ leaf_out)
+// BITS: the new node's position by the bit-board rules on the packed words (go_bits.h: no LDS, no barriers -- for
+// kernels whose workgroup is more than this one wave); else by go_board.h on the wave's LDS board L.
+template <int S, bool BITS>
+__device__ __forceinline__ void select_game(const Tree& t, int g, uint8_t* __restrict__ leaf_out, BoardLds<S>* L)
 {
     using G = Geom<S>;
     static_assert((G::A + 63) / 64 == G::K, "action words must match plane words");
-    __shared__ BoardLds<S> L;
-    board_init_border<S>(L);
-    const int g = blockIdx.x, lane = lane_id();
+    const int lane = lane_id();
     const size_t nb = (size_t)g * t.ncap, rb = (size_t)g * t.rcap;
     int32_t* path = t.path + rb;
     int cur = 0, d = 0;
@@ -143,7 +164,8 @@ __global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict_
         uint64_t nme[G::K], nopp[G::K], ninv[G::K];
         uint32_t nflags = 0;
         int sgn = 0;
-        const int rc = board_next_state<S>(L, me, opp, inv, (uint32_t)(meta & 7u), act, nme, nopp, ninv, nflags, sgn);
+        const int rc = BITS ? uniform_next_state<S>(me, opp, inv, (uint32_t)(meta & 7u), act, nme, nopp, ninv, nflags, sgn)
+                            : board_next_state<S>(*L, me, opp, inv, (uint32_t)(meta & 7u), act, nme, nopp, ninv, nflags, sgn);
         const int idx = t.nnodes[g];
         if (rc != 0 || idx >= t.ncap) {          // cannot happen for a consistent tree; never write out of bounds
             if (lane == 0) atomicAdd(&t.counters[(size_t)2 * t.n_games + g], 1ull);
@@ -196,6 +218,14 @@ __global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict_
     if (leaf_out) planes_store<S>(leaf_out + (size_t)g * 6 * G::P, me, opp, inv, 0, (uint32_t)(meta & 7u));
 }
 
+template <int S>
+__global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict__ leaf_out)
+{
+    __shared__ BoardLds<S> L;
+    board_init_border<S>(L);
+    select_game<S, false>(t, blockIdx.x, leaf_out, &L);
+}
+
 // Node.backprop (/root/reference/go_ai/search/tree.py:141-146) for the selected leaf of game g:
 // every node on the path gets tanh(value) with alternating sign appended to its running
 // numpy-pairwise mean, one lane per ancestor; the parent's PUCT inputs (cN, cQ) are refreshed.
@@ -246,12 +276,11 @@ __device__ __forceinline__ void backprop_path(const Tree& t, int g, double v)
 // straight from the network and RLNet._numpy's post-processing
 // (/root/reference/go_ai/models/__init__.py:90-105) is fused in here.
 template <int S>
-__global__ __launch_bounds__(64) void k_mcts_backup(Tree t, const float* __restrict__ pi_logits,
-                                                    const float* __restrict__ prior_in,
-                                                    const float* __restrict__ val_in, int raw)
+__device__ __forceinline__ void backup_game(const Tree& t, int g, const float* __restrict__ pi_logits,
+                                            const float* __restrict__ prior_in, const float* __restrict__ val_in, int raw)
 {
     using G = Geom<S>;
-    const int g = blockIdx.x, lane = lane_id();
+    const int lane = lane_id();
     const size_t nb = (size_t)g * t.ncap, rb = (size_t)g * t.rcap;
     const int leaf = t.leaf[g];
     uint64_t me[G::K], opp[G::K], inv[G::K], meta;
@@ -314,6 +343,46 @@ __global__ __launch_bounds__(64) void k_mcts_backup(Tree t, const float* __restr
             t.cQ[row + a] = 0.0;
         }
     }
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void k_mcts_backup(Tree t, const float* __restrict__ pi_logits,
+                                                    const float* __restrict__ prior_in,
+                                                    const float* __restrict__ val_in, int raw)
+{
+    backup_game<S>(t, blockIdx.x, pi_logits, prior_in, val_in, raw);
+}
+
+// Between two trunk launches of the lock-step search (actor-critic mode, the context's own network): everything one
+// mct_step does after the trunk and the next one does before it, for the HB = NB0 = 2 games of a workgroup --
+//   heads of this step's leaves -> k_mcts_backup (raw logits) -> k_mcts_select of the NEXT step -> first convolution
+//   of the new leaves
+// -- the same device functions as the four kernels it stands for (same bits out), in one launch: those kernels are
+// latency-bound chains of a few microseconds each, and a workgroup here never waits for another one.  `act` is the
+// trunk's output; the new leaves' first-layer activations go to `act0` (which may be `act`: a workgroup reads its two
+// boards' rows before it overwrites them).
+template <int S>
+__global__ __launch_bounds__(256) void k_post_forward(Tree t, const float* act, HeadWeights hw, const uint4* __restrict__ w0s,
+                                                      const float* __restrict__ b0, float shift, float* act0)
+{
+    static_assert(HB == 2 && NB0 == 2, "two games per workgroup");
+    __shared__ HeadsLds<S> hl;
+    __shared__ Conv0Lds<S> cl;
+    const int n = t.n_active, b_first = blockIdx.x * 2, wave = threadIdx.x >> 6;
+    heads_groups<S>(hl, act, hw, 1, t.pi_logits, t.val_logits, n, b_first, n);          // one group: b_first, b_first + 1
+    // (workgroup-scope ordering is all that is needed: every datum handed from phase to phase stays inside the
+    // workgroup, whose waves share the CU's L1; a device-scope fence would write the XCD's whole dirty L2 back)
+    __threadfence_block();
+    __syncthreads();
+    if (wave < 2 && b_first + wave < n) {
+        const int g = b_first + wave;
+        backup_game<S>(t, g, t.pi_logits, nullptr, t.val_logits, 1);
+        __threadfence_block();              // the descent below reads rows other lanes of this wave have just written
+        select_game<S, true>(t, g, nullptr, nullptr);
+    }
+    __threadfence_block();
+    __syncthreads();
+    conv0_group<S>(cl, t.leaf_planes, w0s, b0, shift, act0, n, b_first);
 }
 
 // rootnode.get_visit_counts() / rootnode.prior_pi / rootnode.visits
@@ -837,6 +906,14 @@ __global__ __launch_bounds__(64) void k_mcts_export(Tree t, int g, int32_t* __re
 
 int launch_mcts_reset(int S_rt, const Tree& t, const uint8_t* roots, hipStream_t st) { LAUNCH_PER_GAME(k_mcts_reset, t, roots); }
 int launch_mcts_select(int S_rt, const Tree& t, uint8_t* leaf_out, hipStream_t st) { LAUNCH_PER_GAME(k_mcts_select, t, leaf_out); }
+int launch_post_forward(int S_rt, const Tree& t, const float* act, const HeadWeights& hw, const void* w0_split, const float* b0,
+                        float shift, float* act0, hipStream_t st)
+{
+    const int grid = (t.n_active + 1) / 2;
+    GOAI_DISPATCH_SIZE(S_rt, k_post_forward<S><<<dim3(grid), dim3(256), 0, st>>>(t, act, hw, (const uint4*)w0_split, b0, shift, act0));
+    GOAI_HIP_CHECK(hipGetLastError());
+    return GOAI_OK;
+}
 int launch_mcts_backup(int S_rt, const Tree& t, const float* pi_logits, const float* prior, const float* val, int raw,
                        hipStream_t st)
 {

@@ -464,6 +464,48 @@ static int timed_conv(goai_ctx* c, const float* in, int l, const float* b, const
 // Raw network outputs for n states (pi may be NULL; always NULL-able for the value net), through the three
 // activation buffers `act` of `cap` boards each.  `timed`: bracket the trunk launches with HIP events
 // when the context's profile is on (creates events, so not for the allocation-free entry point).
+// The residual trunk over the nb boards whose first-layer activations are in act[0]; *out = the buffer (one of the
+// three) that holds the result.
+static int nn_trunk_on(goai_ctx* c, float* const act[3], int nb, bool prof, float** out)
+{
+    Net& net = c->net;
+    const int M = nb * c->P;
+    int rc;
+    float *x = act[0], *y = act[1], *z = act[2];
+    if (net.trunk_fused && net.layers > 0) {
+        // F(3x3,3x3): a workgroup owns whole boards, so all 2 * layers convolutions run in one launch
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (prof) {
+            GOAI_HIP_CHECK(hipEventCreate(&e0));
+            GOAI_HIP_CHECK(hipEventCreate(&e1));
+            c->prof_events.push_back(e0);
+            c->prof_events.push_back(e1);
+            GOAI_HIP_CHECK(hipEventRecord(e0, c->stream));
+        }
+        rc = net.split6
+                 ? launch_conv3x3_wino3s(c->S, x, y, nullptr, net.wt_split6, net.bt, net.wino3p_tab, nb, 2 * net.layers, c->stream)
+             : net.wino3_paired
+                 ? launch_conv3x3_wino3p(c->S, x, y, nullptr, net.wt_wino3, net.bt, net.wino3p_tab, nb, net.n_cu,
+                                         2 * net.layers, c->stream)
+                 : launch_conv3x3_wino3(c->S, x, y, nullptr, net.wt_wino3, net.bt, net.wino3_tab, nb, net.n_cu,
+                                        2 * net.layers, c->stream);
+        if (e1) GOAI_HIP_CHECK(hipEventRecord(e1, c->stream));
+        if (rc) return rc;
+    } else
+    for (int l = 0; l < net.layers; l++) {
+        if (prof) {
+            if ((rc = timed_conv(c, x, 2 * l, net.bt + (size_t)(2 * l) * 128, nullptr, y, M))) return rc;
+            if ((rc = timed_conv(c, y, 2 * l + 1, net.bt + (size_t)(2 * l + 1) * 128, x, z, M))) return rc;
+        } else {
+            if ((rc = conv_any(c, x, 2 * l, net.bt + (size_t)(2 * l) * 128, nullptr, y, M))) return rc;
+            if ((rc = conv_any(c, y, 2 * l + 1, net.bt + (size_t)(2 * l + 1) * 128, x, z, M))) return rc;
+        }
+        float* t = x; x = z; z = t;
+    }
+    *out = x;
+    return GOAI_OK;
+}
+
 static int nn_forward_on(goai_ctx* c, float* const act[3], int cap, bool timed, const uint8_t* states, float* pi,
                          float* val, int n)
 {
@@ -477,42 +519,26 @@ static int nn_forward_on(goai_ctx* c, float* const act[3], int cap, bool timed, 
         int rc;
         if ((rc = launch_conv0(c->S, states + (size_t)done * 6 * P, net.w0, net.w0_split, net.b0, net.shift, act[0], nb, c->stream)))
             return rc;
-        float *x = act[0], *y = act[1], *z = act[2];
-        if (net.trunk_fused && net.layers > 0) {
-            // F(3x3,3x3): a workgroup owns whole boards, so all 2 * layers convolutions run in one launch
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (prof) {
-                GOAI_HIP_CHECK(hipEventCreate(&e0));
-                GOAI_HIP_CHECK(hipEventCreate(&e1));
-                c->prof_events.push_back(e0);
-                c->prof_events.push_back(e1);
-                GOAI_HIP_CHECK(hipEventRecord(e0, c->stream));
-            }
-            rc = net.split6
-                     ? launch_conv3x3_wino3s(c->S, x, y, nullptr, net.wt_split6, net.bt, net.wino3p_tab, nb, 2 * net.layers, c->stream)
-                 : net.wino3_paired
-                     ? launch_conv3x3_wino3p(c->S, x, y, nullptr, net.wt_wino3, net.bt, net.wino3p_tab, nb, net.n_cu,
-                                             2 * net.layers, c->stream)
-                     : launch_conv3x3_wino3(c->S, x, y, nullptr, net.wt_wino3, net.bt, net.wino3_tab, nb, net.n_cu,
-                                            2 * net.layers, c->stream);
-            if (e1) GOAI_HIP_CHECK(hipEventRecord(e1, c->stream));
-            if (rc) return rc;
-        } else
-        for (int l = 0; l < net.layers; l++) {
-            if (prof) {
-                if ((rc = timed_conv(c, x, 2 * l, net.bt + (size_t)(2 * l) * 128, nullptr, y, M))) return rc;
-                if ((rc = timed_conv(c, y, 2 * l + 1, net.bt + (size_t)(2 * l + 1) * 128, x, z, M))) return rc;
-            } else {
-                if ((rc = conv_any(c, x, 2 * l, net.bt + (size_t)(2 * l) * 128, nullptr, y, M))) return rc;
-                if ((rc = conv_any(c, y, 2 * l + 1, net.bt + (size_t)(2 * l + 1) * 128, x, z, M))) return rc;
-            }
-            float* t = x; x = z; z = t;
-        }
+        float* x = nullptr;
+        if ((rc = nn_trunk_on(c, act, nb, prof, &x))) return rc;
         if ((rc = launch_heads(c->S, x, net.hw, net.kind == 0 && pi != nullptr, pi ? pi + (size_t)done * A : nullptr, val + done, nb,
                                c->stream)))
             return rc;
     }
     return GOAI_OK;
+}
+
+// The forward in three pieces on the context's own activation buffers, for the search's fused step (mcts_host.hip):
+// n <= max_batch boards, first convolution into act[0], trunk (timed like nn_forward_raw's), heads.
+int nn_piece_conv0(goai_ctx* c, const uint8_t* states, int n)
+{
+    Net& net = c->net;
+    return launch_conv0(c->S, states, net.w0, net.w0_split, net.b0, net.shift, net.act[0], n, c->stream);
+}
+int nn_piece_trunk(goai_ctx* c, int n, float** out) { return nn_trunk_on(c, c->net.act, n, c->prof_enabled, out); }
+int nn_piece_heads(goai_ctx* c, const float* x, float* pi, float* val, int n)
+{
+    return launch_heads(c->S, x, c->net.hw, c->net.kind == 0 && pi != nullptr, pi, val, n, c->stream);
 }
 
 int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, int n)

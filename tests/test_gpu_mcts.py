@@ -191,3 +191,33 @@ def test_sampled_actions_follow_pi():
     shifted = c.sample_actions(pi, seed=99, step=3, game_id_offset=7).cpu().numpy()
     assert np.array_equal(shifted[:-7], draws[3][7:])
     c.close()
+
+
+@pytest.mark.parametrize("size,games,sims,layers", [(5, 7, 12, 3), (9, 33, 20, 3), (13, 5, 6, 2), (19, 3, 5, 10)])
+def test_fused_step_equals_separate_launches(size, games, sims, layers):
+    """goai_mcts_run with everything between two trunk launches in one kernel (k_post_forward: heads, backup, the next
+    step's select, first convolution) against the same search as separate launches (GOAI_NO_STEP_FUSION=1): visit
+    counts, priors, pi and the search counters bit for bit, odd game counts and every board size included."""
+    import os
+    from go_ai.engine import Context
+    roots = random_positions(size, games, seed=3 + size, max_moves=size * size // 2, canonical=True).astype(np.uint8)
+    sd = nn_ref.make_state_dict("ac", size, 5, layers=layers)
+    outs = []
+    for no_fusion in ("0", "1"):
+        os.environ["GOAI_NO_STEP_FUSION"] = no_fusion
+        try:
+            c = Context(size, 0)
+            c.nn_init(Context.NET_AC, layers, games)
+            c.load_weights(sd)
+            c.mcts_init(games, sims)
+            c.mcts_reset(roots)
+            c.mcts_run(sims)
+            visits, prior, root_visits = [t.cpu().numpy() for t in c.mcts_readout()]
+            outs.append((visits, prior, root_visits, c.mcts_policy(1.0).cpu().numpy(), c.mcts_counters()))
+            c.close()
+        finally:
+            os.environ.pop("GOAI_NO_STEP_FUSION", None)
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert np.array_equal(a, b)
+    assert outs[0][4] == outs[1][4] and outs[0][4]["errors"] == 0
+    assert int(outs[0][2].min()) == sims + 1
