@@ -148,7 +148,8 @@ __device__ __forceinline__ void bits_areas(const BB<S>& a, const BB<S>& b, int& 
 
 // GymGo next_state in the mover-relative frame, one board in this lane (the counterpart of board_next_state,
 // go_board.h: same inputs, same outputs, same return value).  inv_at_action: the state's invalid-plane bit at `action`.
-template <int S, bool AREAS = true>
+// AREAS: 0 no area score (sign_out = 0), 1 always, 2 only where the search reads it (a position after a pass, or a finished game)
+template <int S, int AREAS = 1>
 __device__ __forceinline__ int bits_next_state(const BB<S>& me, const BB<S>& opp, bool inv_at_action, uint32_t flags, int action,
                                                BB<S>& nme, BB<S>& nopp, BB<S>& ninv, uint32_t& nflags, int& sign_out)
 {
@@ -204,7 +205,7 @@ __device__ __forceinline__ int bits_next_state(const BB<S>& me, const BB<S>& opp
     }
     ninv = bb_or(bb_andnot(bb_board<S>(), valid), ko);
     sign_out = 0;
-    if (AREAS) {                                            // area score from the next mover's point of view
+    if (AREAS == 1 || (AREAS == 2 && (nflags & (FLAG_PASS | FLAG_DONE)))) {   // area score from the next mover's point of view
         int a1, a2;
         bits_areas<S>(m, o, a1, a2);
         sign_out = (a2 > a1) - (a2 < a1);

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_transition_lanes(const uint8_t* __restr
     BB<S> nme = bb_zero<S>(), nopp = bb_zero<S>(), ninv = bb_zero<S>();
     uint32_t nflags = 0;
     int sign = 0;
-    const int rc = bits_next_state<S>(me, opp, inv_at, flags, action, nme, nopp, ninv, nflags, sign);
+    const int rc = bits_next_state<S, 0>(me, opp, inv_at, flags, action, nme, nopp, ninv, nflags, sign);
     for (int j = 0; j < nb; j++)
         lane_child_store<S>(out + (size_t)(first + j) * 6 * G::P, j, nme, nopp, ninv, nflags, rc, player, canonical);
     if (lane < nb && status) status[first + lane] = rc;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void k_children_lanes(const uint8_t* __restric
     BB<S> nme = bb_zero<S>(), nopp = bb_zero<S>(), ninv = bb_zero<S>();
     uint32_t nflags = 0;
     int sign = 0;
-    const int rc = bits_next_state<S>(me, opp, inv_at, flags, action, nme, nopp, ninv, nflags, sign);
+    const int rc = bits_next_state<S, 2>(me, opp, inv_at, flags, action, nme, nopp, ninv, nflags, sign);
     for (int j = 0; j < nb; j++)
         lane_child_store<S>(children + (size_t)(first + j) * 6 * G::P, j, nme, nopp, ninv, nflags, rc, player, canonical);
     if (lane < nb) {
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64) void k_transition_staged(const uint8_t* __restr
     BB<S> nme = bb_zero<S>(), nopp = bb_zero<S>(), ninv = bb_zero<S>();
     uint32_t nflags = 0;
     int sign = 0;
-    const int rc = bits_next_state<S, false>(me, opp, inv_at, flags, action, nme, nopp, ninv, nflags, sign);
+    const int rc = bits_next_state<S, 0>(me, opp, inv_at, flags, action, nme, nopp, ninv, nflags, sign);
     const int np = 1 - player;
     const bool keep = canonical || np == 0;                     // the next mover's stones in plane 0
 #pragma unroll 1
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64) void k_children_staged(const uint8_t* __restric
     BB<S> nme = bb_zero<S>(), nopp = bb_zero<S>(), ninv = bb_zero<S>();
     uint32_t nflags = 0;
     int sign = 0;
-    const int rc = bits_next_state<S>(me, opp, inv_at, flags, action, nme, nopp, ninv, nflags, sign);
+    const int rc = bits_next_state<S, 2>(me, opp, inv_at, flags, action, nme, nopp, ninv, nflags, sign);
     const int np = 1 - player;
     const bool keep = canonical || np == 0;
 #pragma unroll 1

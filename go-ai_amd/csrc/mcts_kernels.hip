@@ -27,7 +27,8 @@ __device__ __forceinline__ int uniform_next_state(const uint64_t* me, const uint
 #pragma unroll
     for (int k = 0; k < G::K; k++) { m.w[k] = me[k]; o.w[k] = opp[k]; iv.w[k] = inv[k]; }
     const bool inv_at = action >= 0 && action < G::P && bb_test(iv, action);
-    const int rc = bits_next_state<S, true>(m, o, inv_at, flags, action, a, b, c, nflags, sign_out);
+    // the area sign of a node is read only where the previous move was a pass or the game is over (backup_game)
+    const int rc = bits_next_state<S, 2>(m, o, inv_at, flags, action, a, b, c, nflags, sign_out);
     if (rc == 0) {
 #pragma unroll
         for (int k = 0; k < G::K; k++) { nme[k] = a.w[k]; nopp[k] = b.w[k]; ninv[k] = c.w[k]; }
