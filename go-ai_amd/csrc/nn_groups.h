@@ -153,38 +153,48 @@ __device__ __forceinline__ void heads_groups(HeadsLds<S>& lds, const float* __re
         const int nb = min(HB, nboards - b0);
         __syncthreads();
         // ---- 1x1 convolutions -> h ----
+        // All of a thread's activation loads (64 B per item, up to NLD items in flight) are issued before the first
+        // multiply: issued inside the loop they were one L2 round trip per iteration (6 of them at 9x9).
         const int items = nb * G::P * 8;
-        for (int it0 = 0; it0 < items; it0 += 256) {
-            const int it = it0 + tid;                 // items is a multiple of 8: a cell's 8 lanes are all in or all out
-            const bool on = it < items;
-            const int cellidx = on ? (it >> 3) : 0;   // = board * P + cell
-            const float* src = act + ((size_t)b0 * G::P + cellidx) * 128 + seg * 16;
-            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-            if (on) {
+        constexpr int NIT = (HB * G::P * 8 + 255) / 256, NLD = NIT < 6 ? NIT : 6;
+        for (int it0 = 0; it0 < items; it0 += 256 * NLD) {
+            f32x4 xs[NLD][4];
+#pragma unroll
+            for (int u = 0; u < NLD; u++) {
+                const int it = it0 + u * 256 + tid;       // items is a multiple of 8: a cell's 8 lanes are all in or all out
+                const float* src = act + ((size_t)b0 * G::P + (it < items ? (it >> 3) : 0)) * 128 + seg * 16;
+#pragma unroll
+                for (int i = 0; i < 4; i++) xs[u][i] = *reinterpret_cast<const f32x4*>(src + i * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < NLD; u++) {
+                const int it = it0 + u * 256 + tid;
+                const bool on = it < items;
+                const int cellidx = on ? (it >> 3) : 0;   // = board * P + cell
+                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const f32x4 x = *reinterpret_cast<const f32x4*>(src + i * 4);
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        s0 = fmaf(x[e], w[0][i][e], s0);
-                        s1 = fmaf(x[e], w[1][i][e], s1);
-                        s2 = fmaf(x[e], w[2][i][e], s2);
+                        s0 = fmaf(xs[u][i][e], w[0][i][e], s0);
+                        s1 = fmaf(xs[u][i][e], w[1][i][e], s1);
+                        s2 = fmaf(xs[u][i][e], w[2][i][e], s2);
                     }
                 }
-            }
 #pragma unroll
-            for (int off = 4; off >= 1; off >>= 1) {
-                s0 += __shfl_xor(s0, off);
-                s1 += __shfl_xor(s1, off);
-                s2 += __shfl_xor(s2, off);
-            }
-            if (on && seg == 0) {
-                const int b = cellidx / G::P, p = cellidx - b * G::P;
-                if (is_ac) {
-                    h[b][p] = fmaxf(s0 + cb[0], 0.0f);
-                    h[b][G::P + p] = fmaxf(s1 + cb[1], 0.0f);
+                for (int off = 4; off >= 1; off >>= 1) {
+                    s0 += __shfl_xor(s0, off);
+                    s1 += __shfl_xor(s1, off);
+                    s2 += __shfl_xor(s2, off);
                 }
-                h[b][2 * G::P + p] = fmaxf(s2 + cb[2], 0.0f);
+                if (on && seg == 0) {
+                    const int b = cellidx / G::P, p = cellidx - b * G::P;
+                    if (is_ac) {
+                        h[b][p] = fmaxf(s0 + cb[0], 0.0f);
+                        h[b][G::P + p] = fmaxf(s1 + cb[1], 0.0f);
+                    }
+                    h[b][2 * G::P + p] = fmaxf(s2 + cb[2], 0.0f);
+                }
             }
         }
         __syncthreads();
@@ -198,7 +208,7 @@ __device__ __forceinline__ void heads_groups(HeadsLds<S>& lds, const float* __re
                 float sum[HB];
 #pragma unroll
                 for (int b = 0; b < HB; b++) sum[b] = 0.0f;
-#pragma unroll 6
+#pragma unroll 18
                 for (int j = j0; j < j1; j++) {
                     const float wv = hw.act_lin_wt[(size_t)j * G::A + a];
 #pragma unroll
@@ -222,7 +232,7 @@ __device__ __forceinline__ void heads_groups(HeadsLds<S>& lds, const float* __re
             const float bias = hw.crit_b1[tid];
 #pragma unroll
             for (int b = 0; b < HB; b++) sum[b] = bias;
-#pragma unroll 9
+#pragma unroll 27
             for (int p = 0; p < G::P; p++) {
                 const float wv = hw.crit_w1t[p * 256 + tid];
 #pragma unroll
