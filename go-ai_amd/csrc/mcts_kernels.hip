@@ -362,6 +362,18 @@ __global__ __launch_bounds__(64) void k_mcts_backup(Tree t, const float* __restr
 // latency-bound chains of a few microseconds each, and a workgroup here never waits for another one.  `act` is the
 // trunk's output; the new leaves' first-layer activations go to `act0` (which may be `act`: a workgroup reads its two
 // boards' rows before it overwrites them).
+#ifdef GOAI_PF_STAMPS
+// diagnostic build only (tools/pf_stamps.py): s_memrealtime (100 MHz) at the phase boundaries of every workgroup's last run
+__device__ unsigned long long g_pf_stamps[8 * 8192];
+extern "C" int goai_debug_pf_stamps(unsigned long long* host_out, int n)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pf_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#define PF_STAMP(i) if (threadIdx.x == 0 && blockIdx.x < 8192) g_pf_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define PF_STAMP(i)
+#endif
+
 template <int S>
 __global__ __launch_bounds__(256) void k_post_forward(Tree t, const float* act, HeadWeights hw, const uint4* __restrict__ w0s,
                                                       const float* __restrict__ b0, float shift, float* act0)
@@ -370,20 +382,26 @@ __global__ __launch_bounds__(256) void k_post_forward(Tree t, const float* act, 
     __shared__ HeadsLds<S> hl;
     __shared__ Conv0Lds<S> cl;
     const int n = t.n_active, b_first = blockIdx.x * 2, wave = threadIdx.x >> 6;
+    PF_STAMP(0);
     heads_groups<S>(hl, act, hw, 1, t.pi_logits, t.val_logits, n, b_first, n);          // one group: b_first, b_first + 1
     // (workgroup-scope ordering is all that is needed: every datum handed from phase to phase stays inside the
     // workgroup, whose waves share the CU's L1; a device-scope fence would write the XCD's whole dirty L2 back)
     __threadfence_block();
     __syncthreads();
+    PF_STAMP(1);
     if (wave < 2 && b_first + wave < n) {
         const int g = b_first + wave;
         backup_game<S>(t, g, t.pi_logits, nullptr, t.val_logits, 1);
+        PF_STAMP(2);
         __threadfence_block();              // the descent below reads rows other lanes of this wave have just written
         select_game<S, true>(t, g, nullptr, nullptr);
+        PF_STAMP(3);
     }
     __threadfence_block();
     __syncthreads();
+    PF_STAMP(4);
     conv0_group<S>(cl, t.leaf_planes, w0s, b0, shift, act0, n, b_first);
+    PF_STAMP(5);
 }
 
 // rootnode.get_visit_counts() / rootnode.prior_pi / rootnode.visits
