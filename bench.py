@@ -230,7 +230,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--games", type=int, default=0, help="games per GPU (default: the config's)")
-    ap.add_argument("--dtype", choices=["auto", "f32", "bf16x3", "bf16x6"], default="auto",
+    ap.add_argument("--dtype", choices=["auto", "f32", "bf16x3", "bf16x6", "f16x3"], default="auto",
                     help="arithmetic of the trunk convolutions.  auto = bf16x6 (bf16 matrix cores on operands split exactly "
                          "into three bf16 parts: fp32-grade results, error at the exact-fp32 Winograd kernels' own level); "
                          "f32 = exact fp32 MFMA everywhere; bf16x3 = two-part split (1e-5 class, opt-in)")
@@ -287,7 +287,7 @@ def main():
     n_games = args.games or cfg["games"]
     sp = BatchedSelfPlay(SIZE, n_games, SIMS, temp=1.0, device=local_rank, n_blocks=LAYERS, seed=1234,
                          game_id_offset=rank * n_games, groups=args.groups, search=cfg["search"],
-                         dtype={"f32": 0, "bf16x3": 1, "bf16x6": 2}[args.dtype], refill=not args.no_refill)
+                         dtype={"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}[args.dtype], refill=not args.no_refill)
     sp.randomize_starts(cfg["random_moves"])
     sp.play(args.warmup)
     cnt0 = sp.counters()
@@ -318,7 +318,7 @@ def main():
     peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     algo = sp.ctx.nn_conv_algo()
     kname = {0: "k_conv3x3", 1: "k_conv3x3_wino", 2: "k_conv3x3_bf16", 3: "k_conv3x3_wino3", 4: "k_conv3x3_wino3p",
-             5: "k_conv3x3_wino3s", 6: "k_conv3x3_wino2s"}[algo] + f"<{SIZE}>"
+             5: "k_conv3x3_wino3s", 6: "k_conv3x3_wino2s", 7: "k_conv3x3_wino3s", 8: "k_conv3x3_wino2s"}[algo] + f"<{SIZE}>"
     executed_flop = conv_flop                 # flops the matrix pipe really executes per launch
     if algo == 2:
         executed_flop = 3.0 * conv_flop       # hi*hi + lo*hi + hi*lo on the bf16 pipe
@@ -329,17 +329,17 @@ def main():
         wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // (112 // t2))
         rows = 100 if SIZE in (9, 13, 19) else 112       # six 16-row tiles + one round of 4x4 blocks, or seven tiles
         executed_flop = 2.0 * wgs * rows * 16 * 128 * 128
-    elif algo == 6:
+    elif algo in (6, 8):
         # Winograd F(2x2,3x3) on the bf16 pipe: workgroups of seven 16-column tiles (112 wtile rows), 16 positions, six
         # bf16 products per transform-domain multiply-add
         t2 = ((SIZE + 1) // 2) ** 2
         wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // (112 // t2))
-        executed_flop = 6 * 2.0 * wgs * 112 * 16 * 128 * 128
-    elif algo == 5:
+        executed_flop = (6 if algo == 6 else 3) * 2.0 * wgs * 112 * 16 * 128 * 128
+    elif algo in (5, 7):
         # Winograd F(3x3,3x3) on the bf16 pipe: 4 boards = 36 wtile rows run as three 16-column tiles, six
         # bf16 products (three-way split operands) per transform-domain multiply-add
         wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // 4)
-        executed_flop = 6 * 2.0 * wgs * 48 * 25 * 128 * 128 * cpl
+        executed_flop = (6 if algo == 5 else 3) * 2.0 * wgs * 48 * 25 * 128 * 128 * cpl      # f16x3: three fp16 products on two-way splits
     elif algo in (3, 4):
         # Winograd F(3x3,3x3): 25 products per 3x3 output tile; workgroups of 48 tile rows = 4 boards of 9x9
         # (5 boards once 4 per workgroup would need more than one round of CUs)
@@ -396,6 +396,9 @@ def main():
                           "bf16x6": "fp32 storage; trunk products as 6 bf16 MFMAs on operands split exactly into three bf16 parts, "
                                     "fp32 accumulate and transforms: 6e-6 max rel. error vs the torch fp32 oracle on the 3-block net "
                                     "(the exact-fp32 F(3x3,3x3) kernel: 7e-6), tolerance 1e-3 (tests/test_gpu_nn.py)",
+                          "f16x3": "fp32 storage; trunk products as 3 fp16 MFMAs on operands split into two fp16 parts (22 bits + sign), "
+                                   "scaled by exact powers of two per board, fp32 accumulate and transforms; error vs the torch fp32 "
+                                   "oracle at the exact-fp32 kernels' own level (tests/test_gpu_nn.py), tolerance 1e-3",
                           "bf16x3": "fp32 storage; trunk products as 3 bf16 MFMAs on two-part splits: 2e-5..8e-5 vs torch fp32"}[args.dtype],
             "config": {"workload": f"{cfg['name']}, {n_games} concurrent games per GPU, step = one move of every game "
                                    f"({SIMS + 1} leaf evals per game)",
@@ -415,7 +418,11 @@ def main():
                                        6: "Winograd F(2x2,3x3), bf16 MFMA 16x16x32 on operands split exactly into three bf16 parts "
                                           "(6 products per multiply-add, fp32 accumulate, fp32 transforms): fp32-grade results",
                                        5: "Winograd F(3x3,3x3), bf16 MFMA 16x16x32 on operands split exactly into three bf16 parts "
-                                          "(6 products per multiply-add, fp32 accumulate, fp32 transforms): fp32-grade results"}[algo],
+                                          "(6 products per multiply-add, fp32 accumulate, fp32 transforms): fp32-grade results",
+                                       7: "Winograd F(3x3,3x3), fp16 MFMA 16x16x32 on operands split into two fp16 parts and scaled by "
+                                          "powers of two per board (3 products per multiply-add, fp32 accumulate, fp32 transforms): fp32-grade results",
+                                       8: "Winograd F(2x2,3x3), fp16 MFMA 16x16x32 on operands split into two fp16 parts and scaled by "
+                                          "powers of two per board (3 products per multiply-add, fp32 accumulate, fp32 transforms): fp32-grade results"}[algo],
                          "algorithmic_flop_per_launch": conv_flop,
                          "achieved_algorithmic": round(effective, 2),
                          "note": "achieved / frac count the flops the matrix pipe executes; achieved_algorithmic counts the "

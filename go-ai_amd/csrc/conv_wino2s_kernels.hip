@@ -15,6 +15,11 @@
 //      Tab  16 cell addresses per wtile
 // Weights: [64 stages][8 waves][3 parts][64 lanes][8 bf16] per convolution (nn_host.hip), L2 -> registers one
 // stage ahead into alternating register sets; V fragments are read one tile ahead.
+//
+// NP = 2 (GOAI_DTYPE_F16X3): two fp16 parts per operand, three fp16 MFMAs per tile step, operands scaled by powers of
+// two -- conv_wino3s_kernels.hip explains it; here |Bt d B| <= 4 amax and a launch is one convolution, so the boards'
+// bounds travel between launches in amax_io[board] (read at the start, overwritten with the output's at the end, by
+// the one workgroup that owns the board).
 #include "go_board.h"
 #include "goai_internal.h"
 #include "nn.h"
@@ -23,9 +28,11 @@ namespace goai {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int S>
+template <int S, int NP>
 struct Wino2S {
     static constexpr int T = (S + 1) / 2, T2 = T * T, P = S * S;
     static constexpr int MT = 7, ROWS = MT * 16;                   // wtile rows per workgroup
@@ -34,10 +41,12 @@ struct Wino2S {
     static constexpr int IMG_U4 = NBW * P * 8 + 8;                 // in 16-byte units (+ the zero cell)
     static constexpr int ZERO_U4 = NBW * P * 8;
     static constexpr int V_PART_U4 = ROWS * 4;                     // one (q, part): [ROWS][32 ch] bf16 = 64 B per row
-    static constexpr int V_U4 = 4 * 3 * V_PART_U4;
+    static constexpr int V_U4 = 4 * NP * V_PART_U4;
     static constexpr int TAB_U4 = WT * 2;                          // 16 x u16 LDS addresses per wtile
     static constexpr int NI = (NBW * P * 8 + 511) / 512;           // staged 16-byte pieces per thread per chunk
-    static constexpr int LDS_U4 = IMG_U4 + V_U4 + TAB_U4;
+    static constexpr int AMAX_U4 = 8;                              // [2][16]: input / output bounds of the boards as fp32 bits (NP == 2)
+    static constexpr int LDS_U4 = IMG_U4 + V_U4 + TAB_U4 + AMAX_U4;
+    static_assert(NBW <= 16, "bounds table");
     static_assert(NBW >= 1, "board too large for one workgroup");
     static_assert(LDS_U4 * 16 <= 160 * 1024, "LDS budget");
     static_assert(IMG_U4 * 16 < 65536, "input-transform addresses are 16-bit");
@@ -47,18 +56,22 @@ __device__ __forceinline__ int w2s_swz(int row, int slot) { return row * 8 + (sl
 // two fp32 bit patterns whose low halves are dropped -> one word of two bf16 (a in the low half)
 __device__ __forceinline__ unsigned w2s_pack(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
-template <int S, bool RESID>
+// NP == 2 only: wexp = the weights' scale exponent; amax_first > 0: bound of every board's input, else amax_io[board];
+// amax_io receives the bound of the output, per board.
+template <int S, bool RESID, int NP>
 __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict__ in, const uint4* wt,
                                                         const float* __restrict__ bias,
                                                         const float* __restrict__ resid, float* __restrict__ out,
-                                                        int nboards)
+                                                        int nboards, int wexp, float* amax_io, float amax_first)
 {
-    using W = Wino2S<S>;
+    using W = Wino2S<S, NP>;
     constexpr int P = W::P, MT = W::MT;
     __shared__ f32x4 lds[W::LDS_U4];
     f32x4* Img = lds;
     f32x4* Vs = lds + W::IMG_U4;
     uint16_t* Tab = reinterpret_cast<uint16_t*>(lds + W::IMG_U4 + W::V_U4);
+    unsigned* amax_in = reinterpret_cast<unsigned*>(lds + W::IMG_U4 + W::V_U4 + W::TAB_U4);
+    unsigned* amax_out = amax_in + 16;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
@@ -67,6 +80,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     // V rows WT..ROWS-1 are never written: they stay zero and only reach accumulator columns that are never stored
     for (int i = tid; i < W::V_U4; i += 512) Vs[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
     if (tid < 8) Img[W::ZERO_U4 + tid] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    if (NP == 2 && tid < 16) {
+        const bool on = tid < W::NBW && b_first + tid < nboards;
+        amax_in[tid] = __float_as_uint(!on ? 0.0f : amax_first > 0.0f ? amax_first : amax_io[b_first + tid]);
+        amax_out[tid] = 0u;
+    }
     // Tab[tw][a][b] = byte address in Img (slot 0, before the slot swizzle) of cell (2ty - 1 + a, 2tx - 1 + b) of
     // wtile tw's 4x4 input patch, or of the zero cell when that is off the board
     for (int e = tid; e < W::WT * 16; e += 512) {
@@ -96,7 +114,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < W::NI; i++) {
             const int idx = tid + i * 512;
-            if (idx < W::NBW * P * 8) Img[w2s_swz(idx >> 3, idx & 7)] = ireg[i];
+            if (idx < W::NBW * P * 8) {
+                if constexpr (NP == 2)
+                    Img[w2s_swz(idx >> 3, idx & 7)] =
+                        ireg[i] * __uint_as_float((unsigned)(127 + f16_scale_exp(amax_in[(idx >> 3) / P], 4)) << 23);
+                else
+                    Img[w2s_swz(idx >> 3, idx & 7)] = ireg[i];
+            }
         }
     };
     auto img_at = [&](uint32_t byte_addr) -> f32x4 {
@@ -122,6 +146,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
             r[3] = s1 * img_at(t1.y >> 16) + s2 * img_at(t2.y >> 16);
             uint2* V = reinterpret_cast<uint2*>(Vs) + tw * 8 + ts;
             auto put = [&](int q, const f32x4 v) {
+                if constexpr (NP == 2) {
+                    // two fp16 parts, round to nearest: h = fp16(v), l = fp16(v - h) (the difference is exact in fp32)
+                    const f16x4 h = __builtin_convertvector(v, f16x4);
+                    const f16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), f16x4);
+                    uint2* dst = V + q * (2 * W::V_PART_U4 * 2);
+                    dst[0] = __builtin_bit_cast(uint2, h);
+                    dst[W::V_PART_U4 * 2] = __builtin_bit_cast(uint2, l);
+                } else {
                 unsigned h[4], m[4], l[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -133,7 +165,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
                 uint2* dst = V + q * (3 * W::V_PART_U4 * 2);
                 dst[0] = uint2{ w2s_pack(h[0], h[1]), w2s_pack(h[2], h[3]) };
                 dst[W::V_PART_U4 * 2] = uint2{ w2s_pack(m[0], m[1]), w2s_pack(m[2], m[3]) };
-                dst[2 * W::V_PART_U4 * 2] = uint2{ w2s_pack(l[0], l[1]), w2s_pack(l[2], l[3]) };
+                dst[(NP - 1) * W::V_PART_U4 * 2] = uint2{ w2s_pack(l[0], l[1]), w2s_pack(l[2], l[3]) };
+                }
             };
             put(0, r[0] - r[2]);
             put(1, r[1] + r[2]);
@@ -144,21 +177,20 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
 
     // weights of a stage: the three bf16 parts of U[stage = (chunk * 4 + p) * 4 + q] in the lanes' own order:
     // lane (li, lq) gets output channel 16 wave + li, input channels 8 lq .. 8 lq + 7 of the chunk
-    const uint4* wsrc = wt + wave * 192 + lane;       // [stage][wave][part][lane] x 16 B
-    u32x4 wf[2][3];
+    const uint4* wsrc = wt + wave * (64 * NP) + lane; // [stage][wave][part][lane] x 16 B
+    u32x4 wf[2][NP];
     auto load_b = [&](int stage, u32x4* b) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(wsrc + (size_t)stage * (8 * 192));
-        b[0] = src[0];
-        b[1] = src[64];
-        b[2] = src[128];
+        const u32x4* src = reinterpret_cast<const u32x4*>(wsrc + (size_t)stage * (8 * 64 * NP));
+#pragma unroll
+        for (int r = 0; r < NP; r++) b[r] = src[64 * r];
         // keep the load where it is written (the optimiser would sink it to the loop's end, in front of its use;
         // wt is deliberately not __restrict__: loads from a noalias pointer may cross this fence)
         asm volatile("" ::: "memory");
     };
     auto v_read = [&](int q, int t, uint4* v) {
-        const uint4* V = reinterpret_cast<const uint4*>(Vs) + (q * 3) * W::V_PART_U4 + (t * 16 + li) * 4 + lq;
+        const uint4* V = reinterpret_cast<const uint4*>(Vs) + (q * NP) * W::V_PART_U4 + (t * 16 + li) * 4 + lq;
 #pragma unroll
-        for (int r = 0; r < 3; r++) v[r] = V[r * W::V_PART_U4];
+        for (int r = 0; r < NP; r++) v[r] = V[r * W::V_PART_U4];
     };
 
     f32x4 Y[2][2][MT];                               // [i][j]: output (2ty + i, 2tx + j) of the wtile
@@ -183,7 +215,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
             transform(p);
             __syncthreads();                         // V complete; (p == 3) the image is dead
             if (p == 3 && chunk + 1 < 4) store_img();
-            uint4 vf[2][3];                          // (plain words: a bf16 vector across a branch is re-packed element-wise)
+            uint4 vf[2][NP];                          // (plain words: a bf16 vector across a branch is re-packed element-wise)
             v_read(0, 0, vf[0]);
 #pragma unroll 1
             for (int q2 = 0; q2 < 2; q2++) {
@@ -193,24 +225,33 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
                     const int q = 2 * q2 + qq;
                     const int s = chunk * 16 + p * 4 + q;
                     load_b(s + 1 < 64 ? s + 1 : 63, wf[(qq + 1) & 1]);   // unconditional: the wait counts stay exact
-                    const bf16x8 u0 = __builtin_bit_cast(bf16x8, wf[qq][0]), u1 = __builtin_bit_cast(bf16x8, wf[qq][1]),
-                                 u2 = __builtin_bit_cast(bf16x8, wf[qq][2]);
                     f32x4 m[MT];
 #pragma unroll
                     for (int t = 0; t < MT; t++) {
                         const int n = qq * MT + t;   // tile step of the trip; its fragments sit in vf[n & 1]
                         if (t + 1 < MT) v_read(q, t + 1, vf[(n + 1) & 1]);
                         else v_read(q < 3 ? q + 1 : 3, 0, vf[(n + 1) & 1]);          // (q == 3: a harmless re-read)
-                        const bf16x8 v[3] = { __builtin_bit_cast(bf16x8, vf[n & 1][0]), __builtin_bit_cast(bf16x8, vf[n & 1][1]),
-                                              __builtin_bit_cast(bf16x8, vf[n & 1][2]) };
-                        // the six products of weight up to 2^-16, smallest first
                         f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u2, v[0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[2], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, v[1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, v[0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[1], acc, 0, 0, 0);
-                        m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[0], acc, 0, 0, 0);
+                        if constexpr (NP == 2) {
+                            const f16x8 u0 = __builtin_bit_cast(f16x8, wf[qq][0]), u1 = __builtin_bit_cast(f16x8, wf[qq][1]);
+                            const f16x8 v0 = __builtin_bit_cast(f16x8, vf[n & 1][0]), v1 = __builtin_bit_cast(f16x8, vf[n & 1][1]);
+                            // the three products of weight up to 2^-11, smallest first
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(u1, v0, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(u0, v1, acc, 0, 0, 0);
+                            m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u0, v0, acc, 0, 0, 0);
+                        } else {
+                            const bf16x8 u0 = __builtin_bit_cast(bf16x8, wf[qq][0]), u1 = __builtin_bit_cast(bf16x8, wf[qq][1]),
+                                         u2 = __builtin_bit_cast(bf16x8, wf[qq][NP - 1]);
+                            const bf16x8 v[3] = { __builtin_bit_cast(bf16x8, vf[n & 1][0]), __builtin_bit_cast(bf16x8, vf[n & 1][1]),
+                                                  __builtin_bit_cast(bf16x8, vf[n & 1][NP - 1]) };
+                            // the six products of weight up to 2^-16, smallest first
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u2, v[0], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[2], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, v[1], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, v[0], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[1], acc, 0, 0, 0);
+                            m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[0], acc, 0, 0, 0);
+                        }
                         __builtin_amdgcn_sched_barrier(0);             // keep the pipeline as written
                     }
                     // output transform: Y[i][j] += At[i][p] * At[j][q] * M,  At = (1 1 1 0 ; 0 1 -1 -1); p is unrolled
@@ -250,6 +291,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
         long off[GT][4];
         bool ok[GT][4];
         f32x4 rv[GT][4];
+        int brd[GT];                                         // board of the tile within the workgroup (NP == 2)
 #pragma unroll
         for (int g = 0; g < GT; g++) {
             const int t = t0 + g;
@@ -257,6 +299,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
             const int bl = w / W::T2, rem = w - bl * W::T2;
             const long board = b_first + bl;
             const bool tile_ok = t < MT && w < W::WT && board < nboards;
+            brd[g] = tile_ok ? bl : -1;
             const int ty = rem / W::T, tx = rem - ty * W::T;
 #pragma unroll
             for (int ij = 0; ij < 4; ij++) {
@@ -269,35 +312,68 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
 #pragma unroll
         for (int g = 0; g < GT; g++) {
             if (t0 + g >= MT) continue;
+            // NP == 2: the accumulators are scaled back by 2^-(input scale of the tile's board + weight scale)
+            const int back = NP == 2 ? -(f16_scale_exp(amax_in[brd[g] < 0 ? 0 : brd[g]], 4) + wexp) : 0;
+            float mx = 0.0f;
 #pragma unroll
             for (int ij = 0; ij < 4; ij++) {
-                f32x4 v = Y[ij >> 1][ij & 1][t0 + g] + bv;
+                f32x4 v = Y[ij >> 1][ij & 1][t0 + g];
+                if constexpr (NP == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = __builtin_ldexpf(v[e], back);
+                }
+                v += bv;
                 if (RESID) v += rv[g][ij];
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
-                if (ok[g][ij]) *reinterpret_cast<f32x4*>(&out[off[g][ij]]) = v;
+                if (ok[g][ij]) {
+                    *reinterpret_cast<f32x4*>(&out[off[g][ij]]) = v;
+                    if constexpr (NP == 2) mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+                }
+            }
+            if constexpr (NP == 2) {
+                // the largest value stored for the tile's board: over the four lanes (lq) that hold the tile, then into LDS
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                if (lq == 0 && brd[g] >= 0 && __float_as_uint(mx) > amax_out[brd[g]]) atomicMax(&amax_out[brd[g]], __float_as_uint(mx));
             }
         }
     }
+    if constexpr (NP == 2) {
+        __syncthreads();
+        if (tid < W::NBW && b_first + tid < nboards) amax_io[b_first + tid] = __uint_as_float(amax_out[tid]);
+    }
 }
 
-template <int S>
+template <int S, int NP>
 static int launch_wino2s_size(const float* in, const void* wt_split, const float* bias, const float* resid, float* out,
-                              int nboards, hipStream_t st)
+                              int nboards, hipStream_t st, int wexp, float* amax_io, float amax_first)
 {
-    const int grid = (nboards + Wino2S<S>::NBW - 1) / Wino2S<S>::NBW;
+    const int grid = (nboards + Wino2S<S, NP>::NBW - 1) / Wino2S<S, NP>::NBW;
     const uint4* wt = reinterpret_cast<const uint4*>(wt_split);
-    if (resid) k_conv3x3_wino2s<S, true><<<dim3(grid), dim3(512), 0, st>>>(in, wt, bias, resid, out, nboards);
-    else k_conv3x3_wino2s<S, false><<<dim3(grid), dim3(512), 0, st>>>(in, wt, bias, resid, out, nboards);
+    if (resid)
+        k_conv3x3_wino2s<S, true, NP><<<dim3(grid), dim3(512), 0, st>>>(in, wt, bias, resid, out, nboards, wexp, amax_io, amax_first);
+    else
+        k_conv3x3_wino2s<S, false, NP><<<dim3(grid), dim3(512), 0, st>>>(in, wt, bias, resid, out, nboards, wexp, amax_io, amax_first);
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }
 
-// wt_split: [64 stages][8 waves][3 parts][64 lanes][8 bf16] of one convolution (nn_host.hip)
+// wt_split: [64 stages][8 waves][parts][64 lanes][8 x 16 bit] of one convolution (nn_host.hip).
+// parts = 3: bf16; parts = 2: fp16, which also takes the weights' scale exponent wexp and the boards' bounds
+// amax_io[nboards] (read unless amax_first > 0 bounds every board's input; always written).
 int launch_conv3x3_wino2s(int S_rt, const float* in, const void* wt_split, const float* bias, const float* resid,
-                          float* out, int nboards, hipStream_t st)
+                          float* out, int nboards, hipStream_t st, int parts, int wexp, float* amax_io, float amax_first)
 {
-    GOAI_DISPATCH_SIZE(S_rt, return launch_wino2s_size<S>(in, wt_split, bias, resid, out, nboards, st));
+    if (parts == 2) {
+        if (!amax_io) {
+            set_error("the fp16 F(2x2,3x3) convolution needs the boards' bounds (amax_io)");
+            return GOAI_ERR_ARG;
+        }
+        GOAI_DISPATCH_SIZE(S_rt, return (launch_wino2s_size<S, 2>(in, wt_split, bias, resid, out, nboards, st, wexp, amax_io, amax_first)));
+        return GOAI_OK;
+    }
+    GOAI_DISPATCH_SIZE(S_rt, return (launch_wino2s_size<S, 3>(in, wt_split, bias, resid, out, nboards, st, 0, nullptr, 0.0f)));
     return GOAI_OK;
 }
 

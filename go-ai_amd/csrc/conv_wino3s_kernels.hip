@@ -23,6 +23,25 @@
 // 12 columns read the zero row (the bf16 pipe has cycles to spare; no 4x4 blocks here).
 // Weights: [conv][100 stages][8 waves][3 parts][64 lanes][8 bf16] -- a lane's A operand (its output
 // channel, its 8 input channels) as one 16-byte load per part.
+//
+// NP = 2 (GOAI_DTYPE_F16X3): the same kernel with every operand as TWO fp16 parts and three fp16 MFMAs per tile step,
+//       U V  =  u0 v0 + (u0 v1 + u1 v0)  +  terms below 2^-22 |U V|
+// (h = fp16(x), l = fp16(x - h): 11 + 11 significant bits and the sign of l).  Measured against fp64 it is as close
+// as the six bf16 products and as an fp32 fma chain (tools/ubench/f16x3_accuracy.hip: the fp32 accumulation dominates
+// all three), for half the matrix work, two thirds of the LDS and weight traffic and a cheaper split.  fp16 has five
+// exponent bits, so both operands are SCALED BY POWERS OF TWO (exact) into its range:
+//   weights: per convolution, largest |U| in [2^14, 2^15) -- on the host, exponent in wexp_all[conv];
+//   inputs:  per BOARD and convolution, from an upper bound `amax` of the board's input activations (all >= 0):
+//            |Bt d B| <= 36 amax, so amax in [2^E, 2^(E+1)) is scaled by 2^(9 - E): transformed values below 36864.
+//            The bound of a convolution's input is the maximum its producer stored: the previous epilogue of this
+//            launch (kept in LDS), the previous launch (amax_io, per board) or, for the first convolution of the
+//            trunk, a bound on conv0's output computed from its weights (amax_first: the input planes are 0 / 1).
+//            Transformed values are scaled as they are split, the accumulators are scaled back (v_ldexp_f32) in the
+//            epilogue, which also leaves the next convolution's first two chunks (input channels 0..63 = the output
+//            channels of waves 0..3) in the LDS image regions: only the launch's first convolution stages them from memory.
+// Parts that fall below fp16's normal range (2^-14) lose bits, at an absolute level of 2^-25 of a scaled value range
+// of 2^15: nothing an fp32 sum can see.  The scale of a board depends on that board alone, so its results do not
+// depend on what shares its workgroup or its batch.
 #include <type_traits>
 #include "go_board.h"
 #include "goai_internal.h"
@@ -32,9 +51,11 @@ namespace goai {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int S>
+template <int S, int NP>
 struct Wino3S {
     static_assert(S == 9, "row mapping: 8 + 1 wtiles per board, 4 boards");
     static constexpr int T = S / 3, T2 = T * T, P = S * S;
@@ -44,10 +65,11 @@ struct Wino3S {
     static constexpr int VROWS = WT + 1;                           // the wtile rows + one zero row
     static constexpr int IMG_CH_U4 = 16 + NBW * P * 8;             // 16-byte units per chunk region: two zero cells + cells
     static constexpr int V_PART_U4 = VROWS * 4;                    // one (chunk, q, part): [VROWS][32 ch] bf16 = 64 B per row
-    static constexpr int V_U4 = 2 * 5 * 3 * V_PART_U4;             // [2 chunks][5 q][3 parts]
+    static constexpr int V_U4 = 2 * 5 * NP * V_PART_U4;            // [2 chunks][5 q][NP parts]
     static constexpr int TAB_U4 = WT * 5;                          // [wtile][a] -> 8 x u16 (5 used)
     static constexpr int NI = (NBW * P * 8 + 511) / 512;
-    static constexpr int LDS_U4 = 2 * IMG_CH_U4 + V_U4 + TAB_U4;
+    static constexpr int AMAX_U4 = 2;                              // [2][4 boards] activation bounds as fp32 bits (NP == 2)
+    static constexpr int LDS_U4 = 2 * IMG_CH_U4 + V_U4 + TAB_U4 + AMAX_U4;
     static_assert(LDS_U4 * 16 <= 160 * 1024, "LDS budget");
     static_assert(IMG_CH_U4 * 16 < 65536, "cell addresses and the chunk offset are 16-bit");
 };
@@ -81,19 +103,24 @@ __device__ __forceinline__ f32x4 s_fma4(float c, f32x4 a, f32x4 b)
 // two fp32 bit patterns whose low halves are dropped -> one word of two bf16 (a in the low half)
 __device__ __forceinline__ unsigned s_pack(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
-// Same launch contract as k_conv3x3_wino3 (n_convs convolutions in a row on the same boards).
-template <int S>
+
+// Same launch contract as k_conv3x3_wino3 (n_convs convolutions in a row on the same boards).  NP == 2 only:
+// wexp_all[conv] = the weights' scale exponent; amax_first > 0: bound of the first convolution's input, else
+// amax_io[board]; amax_io != NULL: receives the bound of the last convolution's output, per board.
+template <int S, int NP>
 __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, const float* resid0,
                                                         const uint4* wt_all,
                                                         const float* __restrict__ bias_all,
-                                                        const uint4* __restrict__ tab_g, int nboards, int n_convs)
+                                                        const uint4* __restrict__ tab_g, int nboards, int n_convs,
+                                                        const int* __restrict__ wexp_all, float* amax_io, float amax_first)
 {
-    using W = Wino3S<S>;
+    using W = Wino3S<S, NP>;
     constexpr int P = W::P, MT = W::MT;
     __shared__ f32x4 lds[W::LDS_U4];
     f32x4* Img = lds;                                  // two chunk regions
     f32x4* Vs = lds + 2 * W::IMG_CH_U4;
     uint4* Tab = reinterpret_cast<uint4*>(lds + 2 * W::IMG_CH_U4 + W::V_U4);
+    unsigned* Amax = reinterpret_cast<unsigned*>(lds + 2 * W::IMG_CH_U4 + W::V_U4 + W::TAB_U4);      // [2][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
@@ -105,6 +132,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
     for (int i = tid; i < W::V_U4; i += 512) Vs[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };   // the zero rows stay zero
     if (tid < 32) Img[(tid >> 4) * W::IMG_CH_U4 + (tid & 15)] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };   // the zero cells of both regions
     for (int e = tid; e < W::TAB_U4; e += 512) Tab[e] = tab_g[e];
+    if (NP == 2 && tid < 4) {
+        const bool on = b_first + tid < nboards;
+        Amax[tid] = __float_as_uint(amax_first > 0.0f ? amax_first : (on ? amax_io[b_first + tid] : 0.0f));
+    }
 
     // Input-transform job of this thread: one (wtile, 4-channel slot) item, done for both chunks.  The lanes are laid
     // out for the LDS: a ds_read_b128 is served in four groups of 16 lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}
@@ -136,6 +167,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
             reg[i] = v;
         }
     };
+    const unsigned* amax_in = Amax;                    // this convolution's input bounds: Amax + 4 (k & 1)
     auto store_img_from = [&](int region, const f32x4* reg) {
 #pragma unroll
         for (int i = 0; i < W::NI; i++) {
@@ -148,6 +180,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
     const char* img_lane = reinterpret_cast<const char*>(Img) + ts * 16;
     const uint4* tabrow = Tab + ttw * 5;
     // V[c][q][tw][ts] = (Bt d B)[p][q], q = 0..4, for row p (compile-time after unrolling), chunk region c
+    float t_scale = 1.0f;                              // NP == 2: the scale of this thread's wtile's board, per convolution
     auto transform = [&](int p, int c) {
         if (!t_on) return;
         const char* base = img_lane + c * (W::IMG_CH_U4 * 16);
@@ -187,8 +220,17 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
         }
         // each fp32 value as three bf16 parts (exact: top 16 bits, top 16 bits of the rest, the rest), 4 channels
         // = 8 bytes per part at [row tvrow][channel 4 ts]
-        uint2* V = reinterpret_cast<uint2*>(Vs + c * (5 * 3 * W::V_PART_U4)) + tvrow * 8 + ts;
+        uint2* V = reinterpret_cast<uint2*>(Vs + c * (5 * NP * W::V_PART_U4)) + tvrow * 8 + ts;
         auto put = [&](int q, const f32x4 v) {
+            if constexpr (NP == 2) {
+                // two fp16 parts, round to nearest: h = fp16(v), l = fp16(v - h) (the difference is exact in fp32)
+                const f32x4 vs = v * t_scale;
+                const f16x4 h = __builtin_convertvector(vs, f16x4);
+                const f16x4 l = __builtin_convertvector(vs - __builtin_convertvector(h, f32x4), f16x4);
+                uint2* dst = V + q * (2 * W::V_PART_U4 * 2);
+                dst[0] = __builtin_bit_cast(uint2, h);
+                dst[W::V_PART_U4 * 2] = __builtin_bit_cast(uint2, l);
+            } else {
             unsigned h[4], m[4], l[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -200,7 +242,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
             uint2* dst = (W3S_DIAG & 64) ? reinterpret_cast<uint2*>(Vs) + lane + q * (3 * W::V_PART_U4 * 2) : V + q * (3 * W::V_PART_U4 * 2);
             dst[0] = uint2{ s_pack(h[0], h[1]), s_pack(h[2], h[3]) };
             dst[W::V_PART_U4 * 2] = uint2{ s_pack(m[0], m[1]), s_pack(m[2], m[3]) };
-            dst[2 * W::V_PART_U4 * 2] = uint2{ s_pack(l[0], l[1]), s_pack(l[2], l[3]) };
+            dst[(NP - 1) * W::V_PART_U4 * 2] = uint2{ s_pack(l[0], l[1]), s_pack(l[2], l[3]) };
+            }
         };
         put(0, s_fma4(-2.0f, r[2], s_fma4(2.0f, r[0], r[3] - r[1])));
         put(1, s_fma4(-2.0f, r[1], r[3] - r[2]));
@@ -211,13 +254,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
 
     // weight fragments of a half-stage: the three bf16 parts of U[stage = (chunk * 5 + p) * 5 + q] in the lanes' own
     // order (nn_host.hip): lane (li, lq) gets output channel 16 wave + li, input channels 8 lq .. 8 lq + 7 of the chunk
-    const uint4* wsrc = wt_all + wave * 192 + lane;        // [stage][wave][part][lane] x 16 B: whole lines per load
-    u32x4 wf[2][3];                                        // two half-stages of weights, used alternately
+    const uint4* wsrc = wt_all + wave * (64 * NP) + lane;  // [stage][wave][part][lane] x 16 B: whole lines per load
+    u32x4 wf[2][NP];                                       // two half-stages of weights, used alternately
     auto load_b = [&](int stage, u32x4* b) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(wsrc + (size_t)stage * (8 * 192));
-        b[0] = src[0];
-        b[1] = src[64];
-        b[2] = src[128];
+        const u32x4* src = reinterpret_cast<const u32x4*>(wsrc + (size_t)stage * (8 * 64 * NP));
+#pragma unroll
+        for (int r = 0; r < NP; r++) b[r] = src[64 * r];
         // the optimiser otherwise sinks a load whose value is first used in the next loop iteration down to the
         // loop's end, i.e. right in front of its use (wt_all is deliberately not __restrict__: loads from a
         // noalias pointer may cross this barrier)
@@ -236,18 +278,21 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
     for (int k = 0; k < n_convs; k++) {
     const float* bias = bias_all + k * 128;
     load_b(0, wf[0]);
+    if constexpr (NP == 2) amax_in = Amax + 4 * (k & 1);
     // k = 0: the zero fills and the table are complete; k > 0: every wave's MFMAs of the previous
     // convolution have read V and its stores to `in` are visible to this workgroup
     __syncthreads();
     W3S_STAMP(0);
-    {
+    if (NP == 2 && tid < 4) Amax[4 * ((k + 1) & 1) + tid] = 0u;      // collects this convolution's output bounds (epilogue)
+    if constexpr (NP == 2) t_scale = __uint_as_float((unsigned)(127 + f16_scale_exp(amax_in[ttw / W::T2], 36)) << 23);
+    if (NP != 2 || k == 0) {                         // (NP == 2, k > 0: the previous epilogue left chunks 0 and 1 in LDS)
         f32x4 ireg1[W::NI];                          // both chunks in flight at once: the accumulators are not live yet
         load_img(0);
         load_img_to(1, ireg1);
         store_img(0);
         store_img_from(1, ireg1);
+        __syncthreads();
     }
-    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -277,11 +322,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
             // and the weights of half-stage h + 1 = (q, c) + 1 are requested at the top of half-stage h (two
             // register sets, alternating: no copies, so nothing waits for a load before its data is needed).
             auto v_read = [&](int q, int c, int t, uint4* v) {
-                const uint4* V = reinterpret_cast<const uint4*>(Vs) + ((c * 5 + q) * 3) * W::V_PART_U4 + lq + vrow[t] * 4;
+                const uint4* V = reinterpret_cast<const uint4*>(Vs) + ((c * 5 + q) * NP) * W::V_PART_U4 + lq + vrow[t] * 4;
 #pragma unroll
-                for (int r = 0; r < 3; r++) v[r] = V[r * W::V_PART_U4];
+                for (int r = 0; r < NP; r++) v[r] = V[r * W::V_PART_U4];
             };
-            uint4 vf[2][3];                                        // (kept as plain words: a bf16 vector across a branch is re-packed element-wise)
+            uint4 vf[2][NP];                                        // (kept as plain words: a bf16 vector across a branch is re-packed element-wise)
             v_read(0, 0, 0, vf[0]);
 #pragma unroll 1
             for (int q = 0; q < 5; q++) {
@@ -300,25 +345,37 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
                         else nxt = (2 * (cp + 1)) * 25;
                         if (!(W3S_DIAG & 1)) load_b(nxt < 100 ? nxt : 99, wf[(h + 1) & 1]);     // unconditional: the wait counts stay exact
                     }
-                    const bf16x8 u0 = __builtin_bit_cast(bf16x8, wf[h & 1][0]), u1 = __builtin_bit_cast(bf16x8, wf[h & 1][1]),
-                                 u2 = __builtin_bit_cast(bf16x8, wf[h & 1][2]);
 #pragma unroll
                     for (int t = 0; t < MT; t++) {
                         const int n = h * MT + t;                          // tile step of the row; its fragments sit in vf[n & 1]
-                        if (W3S_DIAG & 4) { vf[(n + 1) & 1][0] = vf[n & 1][0]; vf[(n + 1) & 1][1] = vf[n & 1][1]; vf[(n + 1) & 1][2] = vf[n & 1][2]; }
+                        if (W3S_DIAG & 4) {
+#pragma unroll
+                            for (int r = 0; r < NP; r++) vf[(n + 1) & 1][r] = vf[n & 1][r];
+                        }
                         else if (t + 1 < MT) v_read(q, c, t + 1, vf[(n + 1) & 1]);
                         else if (c == 0) v_read(q, 1, 0, vf[(n + 1) & 1]);
                         else v_read(q < 4 ? q + 1 : 4, 0, 0, vf[(n + 1) & 1]);     // (q == 4: a harmless re-read)
-                        const bf16x8 v[3] = { __builtin_bit_cast(bf16x8, vf[n & 1][0]), __builtin_bit_cast(bf16x8, vf[n & 1][1]),
-                                              __builtin_bit_cast(bf16x8, vf[n & 1][2]) };
-                        // the six products of weight up to 2^-16, smallest first
                         if (W3S_DIAG & 16) { m[t][0] += __uint_as_float(vf[n & 1][0].x ^ wf[h & 1][0].x); continue; }
-                        m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u2, v[0], m[t], 0, 0, 0);
-                        m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[2], m[t], 0, 0, 0);
-                        m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, v[1], m[t], 0, 0, 0);
-                        m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, v[0], m[t], 0, 0, 0);
-                        m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[1], m[t], 0, 0, 0);
-                        m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[0], m[t], 0, 0, 0);
+                        if constexpr (NP == 2) {
+                            const f16x8 u0 = __builtin_bit_cast(f16x8, wf[h & 1][0]), u1 = __builtin_bit_cast(f16x8, wf[h & 1][1]);
+                            const f16x8 v0 = __builtin_bit_cast(f16x8, vf[n & 1][0]), v1 = __builtin_bit_cast(f16x8, vf[n & 1][1]);
+                            // the three products of weight up to 2^-11, smallest first
+                            m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u1, v0, m[t], 0, 0, 0);
+                            m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u0, v1, m[t], 0, 0, 0);
+                            m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u0, v0, m[t], 0, 0, 0);
+                        } else {
+                            const bf16x8 u0 = __builtin_bit_cast(bf16x8, wf[h & 1][0]), u1 = __builtin_bit_cast(bf16x8, wf[h & 1][1]),
+                                         u2 = __builtin_bit_cast(bf16x8, wf[h & 1][NP - 1]);
+                            const bf16x8 v[3] = { __builtin_bit_cast(bf16x8, vf[n & 1][0]), __builtin_bit_cast(bf16x8, vf[n & 1][1]),
+                                                  __builtin_bit_cast(bf16x8, vf[n & 1][NP - 1]) };
+                            // the six products of weight up to 2^-16, smallest first
+                            m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u2, v[0], m[t], 0, 0, 0);
+                            m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[2], m[t], 0, 0, 0);
+                            m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, v[1], m[t], 0, 0, 0);
+                            m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, v[0], m[t], 0, 0, 0);
+                            m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[1], m[t], 0, 0, 0);
+                            m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[0], m[t], 0, 0, 0);
+                        }
                         __builtin_amdgcn_sched_barrier(0);                 // keep the pipeline as written (the scheduler
                     }                                                      // would hoist every read of the row to its top)
                 }
@@ -362,11 +419,22 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
     // `out` may alias `resid` (the trunk's in-place convolutions), so loads and stores stay in program
     // order; the nine residual loads of a tile are issued together, and the residual / no-residual
     // choice is made once, not per cell (conv_wino3p_kernels.hip).
+    // NP == 2: the accumulators are scaled back by 2^-(input scale of the tile's board + weight scale) first, and
+    // the largest value a lane stores per tile goes, reduced over the lanes that share the board, into Amax.
     auto epilogue = [&](auto has_resid) {
         constexpr bool R = decltype(has_resid)::value;
-        auto tile = [&](const f32x4 (&yv)[3][3], const f32x4 bv, long base, bool on) {
+        const int wexp = NP == 2 ? wexp_all[k] : 0;
+        unsigned* amax_out = Amax + 4 * ((k + 1) & 1);
+        // NP == 2: waves 0..3 hold input channels 0..63 of the next convolution of the launch = its chunks 0 and 1: they
+        // also leave their cells in the image regions (dead since the last transform), so the next convolution starts
+        // without a trip through memory.  lcell = the wtile's cell (0, 0) within the workgroup's boards.
+        const bool to_lds = NP == 2 && wave < 4 && k + 1 < n_convs;
+        f32x4* img_next = Img + (wave >> 1) * W::IMG_CH_U4 + 16 + (wave & 1) * 4 + lq;
+        auto tile = [&](const f32x4 (&yv)[3][3], const f32x4 bv, long base, bool on, int board_l, int group_lanes, int lcell) {
             // base = element offset of output (0, 0) of the wtile, this lane's channels
-            if (!on) return;
+            float mx = 0.0f;
+            if (on) {
+            const int back = NP == 2 ? -(f16_scale_exp(amax_in[board_l], 36) + wexp) : 0;
             f32x4 rv[3][3];
             if (R) {
 #pragma unroll
@@ -378,12 +446,29 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
             for (int i = 0; i < 3; i++)
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
-                    f32x4 v = yv[i][j] + bv;
+                    f32x4 v = yv[i][j];
+                    if constexpr (NP == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = __builtin_ldexpf(v[e], back);
+                    }
+                    v += bv;
                     if (R) v += rv[i][j];
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
                     *reinterpret_cast<f32x4*>(&out[base + (i * S + j) * 128]) = v;
+                    if constexpr (NP == 2) {
+                        mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+                        if (to_lds) img_next[(lcell + i * S + j) * 8] = v;
+                    }
                 }
+            }
+            if constexpr (NP == 2) {
+                // lanes of one board: `group_lanes` (8 or 1) consecutive li, all four lq; every lane of the wave takes part
+                for (int d = 1; d < group_lanes; d <<= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                if (on && lq == 0 && (li & (group_lanes - 1)) == 0) atomicMax(&amax_out[board_l], __float_as_uint(mx));
+            }
         };
         const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col]);
 #pragma unroll
@@ -397,7 +482,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
             for (int i = 0; i < 3; i++)
 #pragma unroll
                 for (int j = 0; j < 3; j++) yv[i][j] = Y[i][j][t];
-            tile(yv, bv, (board * P + 3 * ty * S + 3 * tx) * 128 + col, board < nboards);
+            tile(yv, bv, (board * P + 3 * ty * S + 3 * tx) * 128 + col, board < nboards, bl, 8, bl * P + 3 * ty * S + 3 * tx);
         }
         const long board2 = b_first + li;
         f32x4 yv[3][3];
@@ -405,14 +490,18 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
         for (int i = 0; i < 3; i++)
 #pragma unroll
             for (int j = 0; j < 3; j++) yv[i][j] = Y[i][j][2];
-        tile(yv, bv, (board2 * P + 6 * S + 6) * 128 + col, li < 4 && board2 < nboards);   // wtile 8 = (ty, tx) = (2, 2)
+        tile(yv, bv, (board2 * P + 6 * S + 6) * 128 + col, li < 4 && board2 < nboards, li & 3, 1, (li & 3) * P + 6 * S + 6);   // wtile 8 = (ty, tx) = (2, 2)
     };
     if (resid) epilogue(std::true_type{});
     else epilogue(std::false_type{});
     W3S_STAMP(22);
+    if (NP == 2 && k == n_convs - 1 && amax_io) {
+        __syncthreads();
+        if (tid < 4 && b_first + tid < nboards) amax_io[b_first + tid] = __uint_as_float(Amax[4 * ((k + 1) & 1) + tid]);
+    }
     // next convolution of the launch: swap the buffers, step the weights
     if (k & 1) { in = x; out = y; resid = resid0; } else { in = y; out = x; resid = x; }
-    wsrc += (size_t)100 * 8 * 192;
+    wsrc += (size_t)100 * 8 * 64 * NP;
     }
 }
 
@@ -436,21 +525,34 @@ size_t wino3s_build_table(int S_rt, uint16_t* out)
     return (size_t)WT * 5 * 8;
 }
 
-// wt_split: [n_convs][100 stages][8 waves][3 parts][64 lanes][8 bf16] (nn_host.hip); tab: wino3s_build_table.
+// wt_split: [n_convs][100 stages][8 waves][parts][64 lanes][8 x 16 bit] (nn_host.hip); tab: wino3s_build_table.
 // Any number of boards (4 per workgroup, as many rounds of workgroups as it takes).
+// parts = 3: bf16; parts = 2: fp16, which also takes wexp[n_convs] (the weights' scale exponents) and the bound of the
+// first convolution's input, amax_first > 0 or amax_io[nboards]; amax_io (may be NULL) receives the output's bounds.
 int launch_conv3x3_wino3s(int S_rt, float* x, float* y, const float* resid0, const void* wt_split, const float* bias,
-                          const void* tab, int nboards, int n_convs, hipStream_t st)
+                          const void* tab, int nboards, int n_convs, hipStream_t st, int parts, const int* wexp,
+                          float* amax_io, float amax_first)
 {
     if (S_rt != 9 || nboards < 1) {
-        set_error("the bf16x6 F(3x3,3x3) convolution runs 9x9 boards");
+        set_error("the split F(3x3,3x3) convolution runs 9x9 boards");
+        return GOAI_ERR_ARG;
+    }
+    if (parts != 3 && !(parts == 2 && wexp && (amax_first > 0.0f || amax_io))) {
+        set_error("the fp16 F(3x3,3x3) convolution needs its weight exponents and a bound of its input");
         return GOAI_ERR_ARG;
     }
     if (n_convs < 1 || (n_convs > 1 && ((n_convs & 1) || resid0))) {
         set_error("a multi-convolution launch is a whole residual trunk: an even count, no outer residual");
         return GOAI_ERR_ARG;
     }
-    k_conv3x3_wino3s<9><<<dim3((nboards + 3) / 4), dim3(512), 0, st>>>(x, y, resid0, reinterpret_cast<const uint4*>(wt_split), bias,
-                                                                       reinterpret_cast<const uint4*>(tab), nboards, n_convs);
+    if (parts == 2)
+        k_conv3x3_wino3s<9, 2><<<dim3((nboards + 3) / 4), dim3(512), 0, st>>>(x, y, resid0, reinterpret_cast<const uint4*>(wt_split), bias,
+                                                                              reinterpret_cast<const uint4*>(tab), nboards, n_convs,
+                                                                              wexp, amax_io, amax_first);
+    else
+        k_conv3x3_wino3s<9, 3><<<dim3((nboards + 3) / 4), dim3(512), 0, st>>>(x, y, resid0, reinterpret_cast<const uint4*>(wt_split), bias,
+                                                                              reinterpret_cast<const uint4*>(tab), nboards, n_convs,
+                                                                              nullptr, nullptr, 0.0f);
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }

@@ -38,12 +38,29 @@ struct Net {
     bool split6 = false;       // GOAI_DTYPE_BF16X6: F(3x3,3x3) with its products on the bf16 matrix cores, operands split in three
     void* wt_split6 = nullptr; // [2*layers][stages][8 waves][3 parts][64 lanes][8 bf16]: 100 stages for F(3x3,3x3) on 9x9
                                // (conv_wino3s_kernels.hip), 64 for F(2x2,3x3) on the other boards (conv_wino2s_kernels.hip)
+    int parts = 3;             // with split6: 3 bf16 parts per operand, or 2 fp16 parts (GOAI_DTYPE_F16X3: same kernels, same image
+                               // with 2 parts, operands scaled by powers of two into fp16's range)
+    int* wexp = nullptr;       // parts == 2: [2*layers] scale exponents of the weight images (device; wexp_host: the same)
+    int wexp_host[128] = {};
+    float* amax = nullptr;     // parts == 2: [max_batch] upper bound of each board's activations between two launches
+    float amax0 = 0.0f;        // parts == 2: upper bound of conv0's output, from its weights (the input planes are 0 / 1)
     void* wt_bf16 = nullptr;   // bf16x3: [2*layers][4 chunks][9 taps][128 out][32 hi | 32 lo]
     float* bt = nullptr;       // [2*layers][128]
     float* head_blob = nullptr;
     HeadWeights hw{};
     float* act[3] = { nullptr, nullptr, nullptr };   // activation buffers [max_batch*P][128]
 };
+
+// GOAI_DTYPE_F16X3 (conv_wino3s_kernels.hip): exponent of the power of two that scales a board's input activations, all
+// in [0, amax] (amax = the fp32 with bits `amax_bits`), so that Winograd-transformed values, at most `growth` x amax
+// (36 for F(3x3,3x3), 4 for F(2x2,3x3)), stay below fp16's largest number: amax < 2^(E+1) -> 36 * 2^(E+1) * 2^(9-E) = 36864,
+// 4 * 2^(E+1) * 2^(12-E) = 32768.
+__device__ __forceinline__ int f16_scale_exp(unsigned amax_bits, int growth)
+{
+    int e = (int)(amax_bits >> 23);                 // biased exponent: E = e - 127
+    e = e < 16 ? 16 : (e > 250 ? 250 : e);          // the scale stays a normal number
+    return (growth == 36 ? 136 : 139) - e;
+}
 
 int launch_conv0(int S, const uint8_t* states, const float* w0, const void* w0_split, const float* b0, float shift,
                  float* out, int nboards, hipStream_t st);
@@ -69,9 +86,11 @@ int launch_conv3x3_wino3p(int S, float* x, float* y, const float* resid0, const 
                           const void* tab, int nboards, int n_cu, int n_convs, hipStream_t st);
 size_t wino3s_build_table(int S, uint16_t* out);
 int launch_conv3x3_wino3s(int S, float* x, float* y, const float* resid0, const void* wt_split, const float* bias,
-                          const void* tab, int nboards, int n_convs, hipStream_t st);
+                          const void* tab, int nboards, int n_convs, hipStream_t st, int parts = 3, const int* wexp = nullptr,
+                          float* amax_io = nullptr, float amax_first = 0.0f);
 int launch_conv3x3_wino2s(int S, const float* in, const void* wt_split, const float* bias, const float* resid, float* out,
-                          int nboards, hipStream_t st);
+                          int nboards, hipStream_t st, int parts = 3, int wexp = 0, float* amax_io = nullptr,
+                          float amax_first = 0.0f);
 int launch_conv3x3_wino(int S, const float* in, const float* wt_wino, const float* bias, const float* resid, float* out,
                         int nboards, hipStream_t st);
 int launch_heads(int S, const float* act, const HeadWeights& hw, int is_ac, float* pi, float* val, int nboards,

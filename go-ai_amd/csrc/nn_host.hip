@@ -28,8 +28,9 @@ static int dev_alloc(goai_ctx* c, void** p, size_t bytes)
 }
 
 constexpr size_t WT_BF16_PER_CONV = (size_t)2 * 9 * 128 * 128;   // hi and lo halves
-constexpr size_t WT_SPLIT6_PER_CONV = (size_t)100 * 8 * 3 * 64 * 8;   // bf16x6, F(3x3,3x3): three parts of U = G g Gt, lanes' order
-constexpr size_t WT_SPLIT6_F2_PER_CONV = (size_t)64 * 8 * 3 * 64 * 8;  // bf16x6, F(2x2,3x3)
+// split Winograd images, 16-bit elements per convolution: [stages][8 waves][parts][64 lanes][8]; 100 stages for
+// F(3x3,3x3) (4 chunks x 5 x 5), 64 for F(2x2,3x3) (4 chunks x 4 x 4); parts = 3 (bf16x6) or 2 (f16x3)
+static size_t wt_split_per_conv(const Net& n) { return (size_t)(n.wino_mode == 3 ? 100 : 64) * 8 * n.parts * 64 * 8; }
 
 // float -> bfloat16 bits, round to nearest even (what v_cvt_pk_bf16_f32 does on the device)
 static uint16_t bf16_rne(float f)
@@ -90,10 +91,11 @@ static int nn_init_impl(goai_ctx* c, int kind, int layers, int max_batch, int dt
                 prop.multiProcessorCount > 0)
                 n.n_cu = prop.multiProcessorCount;
         }
-        if (dtype == GOAI_DTYPE_BF16X6) {
+        if (dtype == GOAI_DTYPE_BF16X6 || dtype == GOAI_DTYPE_F16X3) {
             // F(3x3,3x3) where it tiles the board exactly (9x9), F(2x2,3x3) elsewhere
             n.wino_mode = wino3_supported(c->S) ? 3 : 2;
             n.split6 = true;
+            n.parts = dtype == GOAI_DTYPE_F16X3 ? 2 : 3;
         }
         if (dtype == GOAI_DTYPE_F32) {
             if (algo && std::string(algo) == "wino") n.wino_mode = 2;
@@ -127,8 +129,11 @@ static int nn_init_impl(goai_ctx* c, int kind, int layers, int max_batch, int dt
             GOAI_HIP_CHECK(hipMemcpy(n.wino3p_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         }
         if (n.split6) {
-            const size_t per_conv = n.wino_mode == 3 ? WT_SPLIT6_PER_CONV : WT_SPLIT6_F2_PER_CONV;
-            if ((rc = dev_alloc(c, &n.wt_split6, (size_t)2 * layers * per_conv * sizeof(uint16_t)))) return rc;
+            if ((rc = dev_alloc(c, &n.wt_split6, (size_t)2 * layers * wt_split_per_conv(n) * sizeof(uint16_t)))) return rc;
+            if (n.parts == 2) {
+                if ((rc = dev_alloc(c, (void**)&n.wexp, (size_t)2 * layers * sizeof(int)))) return rc;
+                if ((rc = dev_alloc(c, (void**)&n.amax, (size_t)max_batch * sizeof(float)))) return rc;
+            }
         } else if (n.wino_mode == 3) {
             if ((rc = dev_alloc(c, (void**)&n.wt_wino3, (size_t)2 * layers * 25 * 128 * 128 * sizeof(float)))) return rc;
             for (int i = 0; i < 2; i++) {
@@ -211,6 +216,19 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
     }
     GOAI_HIP_CHECK(hipMemcpy(net.w0, w0.data(), w0.size() * sizeof(float), hipMemcpyHostToDevice));
     GOAI_HIP_CHECK(hipMemcpy(net.b0, b0.data(), b0.size() * sizeof(float), hipMemcpyHostToDevice));
+    {
+        // no output of conv0 + ReLU exceeds this: its inputs are the six 0 / 1 planes (minus the AC net's shift)
+        double bound = 0.0;
+        for (int co = 0; co < 128; co++) {
+            double hi = b0[co];
+            for (int k = 0; k < 54; k++) {
+                const double wk = w0[k * 128 + co];
+                hi += std::fmax(wk * (1.0 - net.shift), -wk * net.shift);
+            }
+            bound = std::fmax(bound, hi);
+        }
+        net.amax0 = (float)(bound * 1.001) + 1e-30f;
+    }
     if (net.w0_split) {
         // every folded fp32 weight as the exact sum of three bf16 numbers; k = tap * 8 + channel
         std::vector<uint16_t> ws((size_t)3 * 3 * 128 * 32, 0);
@@ -259,70 +277,72 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
                                      wb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             continue;
         }
-        if (net.split6 && net.wino_mode == 2) {
-            // bf16x6 on F(2x2,3x3): U = G g Gt (4x4), G = (1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1), folded and rounded to fp32
-            // as for the fp32 kernel, then cut into three bf16 parts; [stage = (chunk * 4 + p) * 4 + q][wave][part][lane][j]
-            static const double Gm[4][3] = { { 1, 0, 0 }, { 0.5, 0.5, 0.5 }, { 0.5, -0.5, 0.5 }, { 0, 0, 1 } };
-            std::vector<uint16_t> ws(WT_SPLIT6_F2_PER_CONV);
-            for (int co = 0; co < 128; co++)
-                for (int ci = 0; ci < 128; ci++) {
-                    const float* g = &w[((size_t)co * 128 + ci) * 9];
-                    for (int pp = 0; pp < 4; pp++)
-                        for (int qq = 0; qq < 4; qq++) {
-                            double u = 0.0;
-                            for (int ky = 0; ky < 3; ky++)
-                                for (int kx = 0; kx < 3; kx++) u += Gm[pp][ky] * Gm[qq][kx] * (double)g[ky * 3 + kx];
-                            float r = (float)(u * sc[co]);
-                            const int chunk = ci / 32, k = ci % 32;
-                            const size_t stage = (size_t)(chunk * 4 + pp) * 4 + qq;
-                            const size_t lane = (size_t)(k / 8) * 16 + co % 16;
-                            for (int part = 0; part < 3; part++) {
-                                uint32_t bits;
-                                memcpy(&bits, &r, 4);
-                                bits &= 0xffff0000u;
-                                float hf;
-                                memcpy(&hf, &bits, 4);
-                                ws[(((stage * 8 + co / 16) * 3 + part) * 64 + lane) * 8 + k % 8] = (uint16_t)(bits >> 16);
-                                r -= hf;                      // exact
-                            }
-                        }
-                }
-            GOAI_HIP_CHECK(hipMemcpy((uint16_t*)net.wt_split6 + (size_t)l * WT_SPLIT6_F2_PER_CONV, ws.data(),
-                                     ws.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-            continue;
-        }
         if (net.split6) {
-            // bf16x6: the same U = G g Gt, rounded to fp32 as for the fp32 kernels, then cut into three bf16 parts
-            // (top 16 bits, top 16 bits of the rest, the rest: exact); [stage][wave][part][lane (li, lq)][j]:
-            // output channel 16 wave + li, input channel 32 chunk + 8 lq + j -- the lanes' MFMA A operands
+            // U = G g Gt (4x4 for F(2x2,3x3), 5x5 for F(3x3,3x3)), BN scale folded in fp64 and rounded to fp32 as for the
+            // fp32 kernels, then cut into parts; [stage = (chunk * T + p) * T + q][wave][part][lane (li, lq)][j]:
+            // output channel 16 wave + li, input channel 32 chunk + 8 lq + j -- the lanes' MFMA A operands.
+            //   parts = 3: bf16 -- top 16 bits, top 16 bits of the rest, the rest: exact;
+            //   parts = 2: fp16 -- U scaled by 2^wexp so that the largest |U| of the convolution lies in [2^14, 2^15),
+            //              h = fp16(U), l = fp16(U - h), round to nearest.
+            static const double G2[4][3] = { { 1, 0, 0 }, { 0.5, 0.5, 0.5 }, { 0.5, -0.5, 0.5 }, { 0, 0, 1 } };
             static const double G3[5][3] = { { 0.5, 0, 0 }, { -0.5, -0.5, -0.5 }, { -1.0 / 6, 1.0 / 6, -1.0 / 6 },
                                              { 1.0 / 6, 1.0 / 3, 2.0 / 3 }, { 0, 0, 1 } };
-            std::vector<uint16_t> ws(WT_SPLIT6_PER_CONV);
+            const int T = net.wino_mode == 3 ? 5 : 4, parts = net.parts;
+            const size_t per_conv = wt_split_per_conv(net);
+            std::vector<float> uf((size_t)T * T * 128 * 128);                 // [p][q][co][ci]
+            float umax = 0.0f;
             for (int co = 0; co < 128; co++)
                 for (int ci = 0; ci < 128; ci++) {
                     const float* g = &w[((size_t)co * 128 + ci) * 9];
-                    for (int pp = 0; pp < 5; pp++)
-                        for (int qq = 0; qq < 5; qq++) {
+                    for (int pp = 0; pp < T; pp++)
+                        for (int qq = 0; qq < T; qq++) {
                             double u = 0.0;
                             for (int ky = 0; ky < 3; ky++)
-                                for (int kx = 0; kx < 3; kx++) u += G3[pp][ky] * G3[qq][kx] * (double)g[ky * 3 + kx];
-                            float r = (float)(u * sc[co]);
-                            const int chunk = ci / 32, k = ci % 32;
-                            const size_t stage = (size_t)(chunk * 5 + pp) * 5 + qq;
-                            const size_t lane = (size_t)(k / 8) * 16 + co % 16;
-                            for (int part = 0; part < 3; part++) {
-                                uint32_t bits;
-                                memcpy(&bits, &r, 4);
-                                bits &= 0xffff0000u;
-                                float hf;
-                                memcpy(&hf, &bits, 4);
-                                ws[(((stage * 8 + co / 16) * 3 + part) * 64 + lane) * 8 + k % 8] = (uint16_t)(bits >> 16);
-                                r -= hf;                      // exact
-                            }
+                                for (int kx = 0; kx < 3; kx++)
+                                    u += (T == 5 ? G3[pp][ky] * G3[qq][kx] : G2[pp][ky] * G2[qq][kx]) * (double)g[ky * 3 + kx];
+                            const float r = (float)(u * sc[co]);
+                            uf[(((size_t)pp * T + qq) * 128 + co) * 128 + ci] = r;
+                            umax = std::fmax(umax, std::fabs(r));
                         }
                 }
-            GOAI_HIP_CHECK(hipMemcpy((uint16_t*)net.wt_split6 + (size_t)l * WT_SPLIT6_PER_CONV, ws.data(),
-                                     ws.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            int wexp = 0;
+            if (parts == 2) {
+                GOAI_REQUIRE(std::isfinite(umax), "non-finite convolution weights");
+                int ex = 0;
+                if (umax > 0.0f) std::frexp(umax, &ex);                        // umax in [2^(ex-1), 2^ex)
+                wexp = 15 - ex;
+                wexp = wexp > 100 ? 100 : wexp;
+                net.wexp_host[l] = wexp;
+                GOAI_HIP_CHECK(hipMemcpy(net.wexp + l, &wexp, sizeof(int), hipMemcpyHostToDevice));
+            }
+            std::vector<uint16_t> ws(per_conv);
+            for (int pp = 0; pp < T; pp++)
+                for (int qq = 0; qq < T; qq++)
+                    for (int co = 0; co < 128; co++)
+                        for (int ci = 0; ci < 128; ci++) {
+                            float r = uf[(((size_t)pp * T + qq) * 128 + co) * 128 + ci];
+                            const int chunk = ci / 32, k = ci % 32;
+                            const size_t stage = (size_t)(chunk * T + pp) * T + qq;
+                            const size_t lane = (size_t)(k / 8) * 16 + co % 16;
+                            uint16_t* dst = &ws[(((stage * 8 + co / 16) * parts) * 64 + lane) * 8 + k % 8];
+                            if (parts == 2) {
+                                r = std::ldexp(r, wexp);
+                                const _Float16 h = (_Float16)r, lo = (_Float16)(r - (float)h);
+                                memcpy(dst, &h, 2);
+                                memcpy(dst + 64 * 8, &lo, 2);
+                            } else
+                                for (int part = 0; part < 3; part++) {
+                                    uint32_t bits;
+                                    memcpy(&bits, &r, 4);
+                                    bits &= 0xffff0000u;
+                                    float hf;
+                                    memcpy(&hf, &bits, 4);
+                                    dst[(size_t)part * 64 * 8] = (uint16_t)(bits >> 16);
+                                    r -= hf;                      // exact
+                                }
+                        }
+            GOAI_HIP_CHECK(hipMemcpy((uint16_t*)net.wt_split6 + (size_t)l * per_conv, ws.data(), ws.size() * sizeof(uint16_t),
+                                     hipMemcpyHostToDevice));
             continue;
         }
         if (net.wino_mode == 3) {
@@ -429,13 +449,14 @@ static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const f
         return launch_conv3x3_bf16(c->S, in, (const uint16_t*)net.wt_bf16 + (size_t)l * WT_BF16_PER_CONV, b, resid, out, M,
                                    c->stream);
     const bool wino = net.wino_mode == 2;
+    // fp16 parts: the first convolution's input is bounded by amax0, every launch leaves its output's bounds in net.amax
     if (net.split6 && net.wino_mode == 2)
-        return launch_conv3x3_wino2s(c->S, in, (const uint16_t*)net.wt_split6 + (size_t)l * WT_SPLIT6_F2_PER_CONV, b, resid, out,
-                                     M / c->P, c->stream);
+        return launch_conv3x3_wino2s(c->S, in, (const uint16_t*)net.wt_split6 + (size_t)l * wt_split_per_conv(net), b, resid, out,
+                                     M / c->P, c->stream, net.parts, net.wexp_host[l], net.amax, l == 0 ? net.amax0 : 0.0f);
     if (net.split6)
         return launch_conv3x3_wino3s(c->S, const_cast<float*>(in), out, resid,
-                                     (const uint16_t*)net.wt_split6 + (size_t)l * WT_SPLIT6_PER_CONV, b, net.wino3p_tab, M / c->P, 1,
-                                     c->stream);
+                                     (const uint16_t*)net.wt_split6 + (size_t)l * wt_split_per_conv(net), b, net.wino3p_tab, M / c->P, 1,
+                                     c->stream, net.parts, net.wexp + l, net.amax, l == 0 ? net.amax0 : 0.0f);
     if (net.wino3_paired)
         return launch_conv3x3_wino3p(c->S, const_cast<float*>(in), out, resid, net.wt_wino3 + (size_t)l * 25 * 128 * 128, b,
                                      net.wino3p_tab, M / c->P, net.n_cu, 1, c->stream);
@@ -483,7 +504,8 @@ static int nn_trunk_on(goai_ctx* c, float* const act[3], int nb, bool prof, floa
             GOAI_HIP_CHECK(hipEventRecord(e0, c->stream));
         }
         rc = net.split6
-                 ? launch_conv3x3_wino3s(c->S, x, y, nullptr, net.wt_split6, net.bt, net.wino3p_tab, nb, 2 * net.layers, c->stream)
+                 ? launch_conv3x3_wino3s(c->S, x, y, nullptr, net.wt_split6, net.bt, net.wino3p_tab, nb, 2 * net.layers, c->stream,
+                                         net.parts, net.wexp, nullptr, net.amax0)
              : net.wino3_paired
                  ? launch_conv3x3_wino3p(c->S, x, y, nullptr, net.wt_wino3, net.bt, net.wino3p_tab, nb, net.n_cu,
                                          2 * net.layers, c->stream)

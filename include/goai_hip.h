@@ -98,6 +98,12 @@ int goai_liberties(goai_ctx* ctx, const uint8_t* states, int32_t* black_libs, in
                              * parts each (24 significant bits; the dropped cross terms are below 2^-24 of a product),
                              * fp32 accumulate, fp32 transforms.  Outputs agree with the exact-fp32 kernels at their own
                              * rounding level (tests/test_gpu_nn.py).  F(3x3,3x3) on 9x9 boards, F(2x2,3x3) on the others. */
+#define GOAI_DTYPE_F16X3 3  /* the same Winograd kernels with every operand as TWO fp16 parts (h = fp16(x), l = fp16(x - h): 22
+                             * significant bits and a sign) and THREE fp16 MFMAs per product, operands scaled by exact powers
+                             * of two into fp16's range (weights per convolution, activations per board and convolution from
+                             * a running upper bound).  Half the matrix work of GOAI_DTYPE_BF16X6 at the same measured
+                             * accuracy: in both, the fp32 accumulation dominates the error (tests/test_gpu_nn.py,
+                             * tools/ubench/f16x3_accuracy.hip). */
 #define GOAI_NN_RAW 0       /* the nn.Module outputs (ac_net.forward / val_net.forward) */
 #define GOAI_NN_NUMPY_SHIM 1 /* + RLNet._numpy post-processing, models/__init__.py:90-105 */
 
@@ -120,6 +126,8 @@ int goai_nn_init(goai_ctx* ctx, int net_kind, int n_blocks, int max_batch, int d
 #define GOAI_CONV_WINOGRAD_F3_PAIRED 4 /* the same with two 32-channel chunks per output transform: 9x9, max_batch <= 4 boards per CU */
 #define GOAI_CONV_WINOGRAD_F3_BF16X6 5 /* GOAI_DTYPE_BF16X6 contexts, 9x9: F(3x3,3x3) */
 #define GOAI_CONV_WINOGRAD_BF16X6 6    /* GOAI_DTYPE_BF16X6 contexts, other boards: F(2x2,3x3) */
+#define GOAI_CONV_WINOGRAD_F3_F16X3 7  /* GOAI_DTYPE_F16X3 contexts, 9x9: F(3x3,3x3) */
+#define GOAI_CONV_WINOGRAD_F16X3 8     /* GOAI_DTYPE_F16X3 contexts, other boards: F(2x2,3x3) */
 int goai_nn_conv_algo(goai_ctx* ctx);
 
 /* How many of the trunk's 3x3 convolutions one kernel launch of this context runs (no reference

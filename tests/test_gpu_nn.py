@@ -316,24 +316,30 @@ def test_f3_paired_output_does_not_depend_on_position_in_batch():
     (13, "ac", 45, 3, 64), (13, "val", 7, 3, 8), (13, "ac", 300, 3, 512),     # F(2x2,3x3): 2 boards per workgroup, odd counts
     (19, "ac", 9, 3, 16), (19, "ac", 5, 10, 8), (19, "ac", 130, 10, 256),     # 1 board per workgroup; the deeper trunk
     (5, "ac", 77, 3, 256), (7, "ac", 50, 3, 64)])
-def test_bf16x6_forward_is_fp32_grade(size, kind, n, layers, max_batch, monkeypatch):
+@pytest.mark.parametrize("split", ["bf16x6", "f16x3"])
+def test_split_forward_is_fp32_grade(size, kind, n, layers, max_batch, split, monkeypatch):
     """GOAI_DTYPE_BF16X6 (conv_wino3s_kernels.hip on 9x9, conv_wino2s_kernels.hip elsewhere): Winograd whose
     transform-domain products run on the bf16 matrix cores with every operand split exactly into three bf16
     parts (six products, fp32 accumulate).  Bound: the fp32 tolerance of BASELINE.json (1e-3) against the torch
     fp32 oracle -- and, the claim that makes it an fp32 path: its error is at the level of the exact-fp32 Winograd
     kernel's own error (same transforms, same rounding points; the dropped cross terms are below 2^-24 of a
-    product), on the reference's 3-block net and on the 10-block net alike."""
+    product), on the reference's 3-block net and on the 10-block net alike.
+    GOAI_DTYPE_F16X3: the same kernels with two fp16 parts per operand (three products), operands scaled by powers of
+    two per board; held to the same bound."""
     from go_ai.engine import Context
+    split_dtype = Context.DTYPE_BF16X6 if split == "bf16x6" else Context.DTYPE_F16X3
+    algos = ((Context.CONV_WINOGRAD_F3_BF16X6, Context.CONV_WINOGRAD_BF16X6) if split == "bf16x6"
+             else (Context.CONV_WINOGRAD_F3_F16X3, Context.CONV_WINOGRAD_F16X3))
     states = random_positions(size, n, seed=size * 7 + n, canonical=True, pass_prob=0.05)
     outs = {}
-    for name, dtype, algo in (("split", Context.DTYPE_BF16X6, None), ("fp32", Context.DTYPE_F32, "wino3" if size == 9 else "wino")):
+    for name, dtype, algo in (("split", split_dtype, None), ("fp32", Context.DTYPE_F32, "wino3" if size == 9 else "wino")):
         if algo:
             monkeypatch.setenv("GOAI_CONV_ALGO", algo)
         else:
             monkeypatch.delenv("GOAI_CONV_ALGO", raising=False)
         c, sd = make_ctx(kind, size, 100 + size + layers, layers, max_batch, dtype=dtype)
         if name == "split":
-            assert c.nn_conv_algo() == (Context.CONV_WINOGRAD_F3_BF16X6 if size == 9 else Context.CONV_WINOGRAD_BF16X6)
+            assert c.nn_conv_algo() == (algos[0] if size == 9 else algos[1])
             assert c.nn_convs_per_launch() == (2 * layers if size == 9 else 1)
         pi, val = c.nn_forward(states, mode=c.NN_RAW)
         outs[name] = (pi.cpu().numpy() if kind == "ac" else None, val.cpu().numpy())
@@ -350,6 +356,6 @@ def test_bf16x6_forward_is_fp32_grade(size, kind, n, layers, max_batch, monkeypa
         ep = rel_err(outs[name][0], want_pi.numpy()) if kind == "ac" else 0.0
         err[name] = max(ev, ep)
     between = max(rel_err(outs["split"][1], outs["fp32"][1]), rel_err(outs["split"][0], outs["fp32"][0]) if kind == "ac" else 0.0)
-    print(f"bf16x6 {kind}{size} L{layers} n={n}: vs torch {err['split']:.2e} (exact-fp32 Winograd: {err['fp32']:.2e}), between them {between:.2e}")
+    print(f"{split} {kind}{size} L{layers} n={n}: vs torch {err['split']:.2e} (exact-fp32 Winograd: {err['fp32']:.2e}), between them {between:.2e}")
     assert err["split"] < REL_TOL
     assert err["split"] < 2.0 * err["fp32"] + 2e-6      # at the fp32 kernel's own level

@@ -1,5 +1,5 @@
 """Diagnostic (needs a -DGOAI_CONV_STAMPS build of conv_wino3s_kernels.hip in the library named by GOAI_HIP_LIB,
-see tools/wino3s_stamps.sh): phases of the second convolution of the bf16x6 F(3x3,3x3) trunk launch, from
+see tools/wino3s_stamps.sh): phases of the second convolution of the split F(3x3,3x3) trunk launch (DTYPE=f16x3 | bf16x6), from
 s_memrealtime stamps (100 MHz)."""
 import ctypes, os, sys
 import numpy as np, torch
@@ -9,8 +9,9 @@ from go_ai import _hip
 from go_ai.engine import Context
 from go_ai.models import random_state_dict
 NB = int(os.environ.get("NB", "1024"))
-c = Context(9); c.nn_init(0, 3, 1024, dtype=Context.DTYPE_BF16X6); c.load_weights(random_state_dict("ac", 9, 0))
-assert c.nn_conv_algo() == Context.CONV_WINOGRAD_F3_BF16X6
+F16 = os.environ.get("DTYPE", "f16x3") == "f16x3"
+c = Context(9); c.nn_init(0, 3, 1024, dtype=Context.DTYPE_F16X3 if F16 else Context.DTYPE_BF16X6); c.load_weights(random_state_dict("ac", 9, 0))
+assert c.nn_conv_algo() == (Context.CONV_WINOGRAD_F3_F16X3 if F16 else Context.CONV_WINOGRAD_F3_BF16X6)
 st = torch.from_numpy((np.random.default_rng(0).random((NB, 6, 9, 9)) < 0.3).astype(np.uint8)).cuda()
 for _ in range(3): c.nn_forward(st)
 torch.cuda.synchronize()
@@ -33,5 +34,5 @@ for r in range(10):
 print(f"epilogue            {med[22] - med[21]:7.2f} us")
 print(f"layer               {med[22]:7.2f} us   (transforms {sum(tr):.1f}, stages {sum(stg):.1f})")
 cyc = np.median((a[:, 24] - a[:, 23]).astype(float)); us = np.median((a[:, 22] - a[:, 0]) / 100.0)
-print(f"in-kernel clock {cyc / us / 1e3:.3f} GHz; a stage = {sum(stg) / 50 * cyc / us:.0f} shader cycles (its 36 MFMAs x 2 waves need 1,152 per SIMD)")
+print(f"in-kernel clock {cyc / us / 1e3:.3f} GHz; a stage = {sum(stg) / 50 * cyc / us:.0f} shader cycles (its {18 if F16 else 36} MFMAs x 2 waves need {576 if F16 else 1152} per SIMD)")
 print(f"spread over workgroups of the layer time: min {t[:, 22].min():.1f} max {t[:, 22].max():.1f}")
