@@ -318,16 +318,23 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
                 load_img(3);
             }
             // The row's five stages as 30 tile steps (q, chunk c, column tile t), fully unrolled and software-
-            // pipelined: the three V fragments of step n + 1 are read from LDS while the six MFMAs of step n run,
-            // and the weights of half-stage h + 1 = (q, c) + 1 are requested at the top of half-stage h (two
-            // register sets, alternating: no copies, so nothing waits for a load before its data is needed).
+            // pipelined: the V fragments of step n + AH are read from LDS while the MFMAs of step n run, and the weights of
+            // half-stage h + 1 = (q, c) + 1 are requested at the top of half-stage h (two register sets,
+            // alternating: no copies, so nothing waits for a load before its data is needed).
+            constexpr int AH = 1, RING = AH + 1;               // (AH = 2 with three MFMAs per step: measured 2 % slower)
             auto v_read = [&](int q, int c, int t, uint4* v) {
                 const uint4* V = reinterpret_cast<const uint4*>(Vs) + ((c * 5 + q) * NP) * W::V_PART_U4 + lq + vrow[t] * 4;
 #pragma unroll
                 for (int r = 0; r < NP; r++) v[r] = V[r * W::V_PART_U4];
             };
-            uint4 vf[2][NP];                                        // (kept as plain words: a bf16 vector across a branch is re-packed element-wise)
-            v_read(0, 0, 0, vf[0]);
+            // step nn = 3 c + t of stage q; nn >= 6: of the next stage (q == 4: a harmless re-read)
+            auto v_read_step = [&](int q, int nn, uint4* v) {
+                if (nn >= 2 * MT) v_read(q < 4 ? q + 1 : 4, (nn - 2 * MT) / MT, (nn - 2 * MT) % MT, v);
+                else v_read(q, nn / MT, nn % MT, v);
+            };
+            uint4 vf[RING][NP];                                     // (kept as plain words: a bf16 vector across a branch is re-packed element-wise)
+#pragma unroll
+            for (int a = 0; a < AH; a++) v_read_step(0, a, vf[a]);
 #pragma unroll 1
             for (int q = 0; q < 5; q++) {
                 f32x4 m[MT];
@@ -347,18 +354,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
                     }
 #pragma unroll
                     for (int t = 0; t < MT; t++) {
-                        const int n = h * MT + t;                          // tile step of the row; its fragments sit in vf[n & 1]
+                        const int n = h * MT + t;                          // tile step of the stage; its fragments sit in vf[n % RING]
                         if (W3S_DIAG & 4) {
 #pragma unroll
-                            for (int r = 0; r < NP; r++) vf[(n + 1) & 1][r] = vf[n & 1][r];
+                            for (int r = 0; r < NP; r++) vf[(n + AH) % RING][r] = vf[n % RING][r];
                         }
-                        else if (t + 1 < MT) v_read(q, c, t + 1, vf[(n + 1) & 1]);
-                        else if (c == 0) v_read(q, 1, 0, vf[(n + 1) & 1]);
-                        else v_read(q < 4 ? q + 1 : 4, 0, 0, vf[(n + 1) & 1]);     // (q == 4: a harmless re-read)
-                        if (W3S_DIAG & 16) { m[t][0] += __uint_as_float(vf[n & 1][0].x ^ wf[h & 1][0].x); continue; }
+                        else v_read_step(q, n + AH, vf[(n + AH) % RING]);
+                        // the reads go out before the step's first MFMA, not (as the scheduler would have it, to shorten live
+                        // ranges) before its last
+                        if constexpr (NP == 2) __builtin_amdgcn_sched_barrier(0);
+                        if (W3S_DIAG & 16) { m[t][0] += __uint_as_float(vf[n % RING][0].x ^ wf[h & 1][0].x); continue; }
                         if constexpr (NP == 2) {
                             const f16x8 u0 = __builtin_bit_cast(f16x8, wf[h & 1][0]), u1 = __builtin_bit_cast(f16x8, wf[h & 1][1]);
-                            const f16x8 v0 = __builtin_bit_cast(f16x8, vf[n & 1][0]), v1 = __builtin_bit_cast(f16x8, vf[n & 1][1]);
+                            const f16x8 v0 = __builtin_bit_cast(f16x8, vf[n % RING][0]), v1 = __builtin_bit_cast(f16x8, vf[n % RING][1]);
                             // the three products of weight up to 2^-11, smallest first
                             m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u1, v0, m[t], 0, 0, 0);
                             m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u0, v1, m[t], 0, 0, 0);
@@ -366,8 +374,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
                         } else {
                             const bf16x8 u0 = __builtin_bit_cast(bf16x8, wf[h & 1][0]), u1 = __builtin_bit_cast(bf16x8, wf[h & 1][1]),
                                          u2 = __builtin_bit_cast(bf16x8, wf[h & 1][NP - 1]);
-                            const bf16x8 v[3] = { __builtin_bit_cast(bf16x8, vf[n & 1][0]), __builtin_bit_cast(bf16x8, vf[n & 1][1]),
-                                                  __builtin_bit_cast(bf16x8, vf[n & 1][NP - 1]) };
+                            const bf16x8 v[3] = { __builtin_bit_cast(bf16x8, vf[n % RING][0]), __builtin_bit_cast(bf16x8, vf[n % RING][1]),
+                                                  __builtin_bit_cast(bf16x8, vf[n % RING][NP - 1]) };
                             // the six products of weight up to 2^-16, smallest first
                             m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u2, v[0], m[t], 0, 0, 0);
                             m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[2], m[t], 0, 0, 0);
