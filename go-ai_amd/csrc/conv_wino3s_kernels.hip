@@ -254,12 +254,17 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
 
     // weight fragments of a half-stage: the three bf16 parts of U[stage = (chunk * 5 + p) * 5 + q] in the lanes' own
     // order (nn_host.hip): lane (li, lq) gets output channel 16 wave + li, input channels 8 lq .. 8 lq + 7 of the chunk
-    const uint4* wsrc = wt_all + wave * (64 * NP) + lane;  // [stage][wave][part][lane] x 16 B: whole lines per load
+    // [stage][wave][part][lane] x 16 B: whole lines per load, as buffer loads: descriptor = this convolution's image,
+    // scalar offset = the stage, vector offset = the lane's place in the stage -- no address arithmetic in the loop
+    const uint4* wconv = wt_all;
+    const unsigned wlane = (wave * (64 * NP) + lane) * 16;        // bytes
+    constexpr unsigned W_STAGE_BYTES = 8 * 64 * NP * 16, W_CONV_BYTES = 100 * W_STAGE_BYTES;
+    auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wconv), 0, W_CONV_BYTES, 0x00020000);
     u32x4 wf[2][NP];                                       // two half-stages of weights, used alternately
     auto load_b = [&](int stage, u32x4* b) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(wsrc + (size_t)stage * (8 * 64 * NP));
 #pragma unroll
-        for (int r = 0; r < NP; r++) b[r] = src[64 * r];
+        for (int r = 0; r < NP; r++)
+            b[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024 * r, stage * W_STAGE_BYTES, 0));
         // the optimiser otherwise sinks a load whose value is first used in the next loop iteration down to the
         // loop's end, i.e. right in front of its use (wt_all is deliberately not __restrict__: loads from a
         // noalias pointer may cross this barrier)
@@ -273,6 +278,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
     vrow[0] = li;
     vrow[1] = 16 + li;
     vrow[2] = li < 4 ? 32 + li : W::WT;              // the zero row
+    unsigned vaddr[MT];                              // LDS byte address of the lane's fragment of (chunk 0, q 0, part 0) per column tile
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        vaddr[t] = (unsigned)((2 * W::IMG_CH_U4 + lq + vrow[t] * 4) * 16);
+        asm volatile("" : "+v"(vaddr[t]));           // (a register, not a constant to be folded into each read's address again)
+    }
 
 #pragma unroll 1
     for (int k = 0; k < n_convs; k++) {
@@ -322,19 +333,24 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
             // half-stage h + 1 = (q, c) + 1 are requested at the top of half-stage h (two register sets,
             // alternating: no copies, so nothing waits for a load before its data is needed).
             constexpr int AH = 1, RING = AH + 1;               // (AH = 2 with three MFMAs per step: measured 2 % slower)
-            auto v_read = [&](int q, int c, int t, uint4* v) {
-                const uint4* V = reinterpret_cast<const uint4*>(Vs) + ((c * 5 + q) * NP) * W::V_PART_U4 + lq + vrow[t] * 4;
+            // vq[t] = LDS byte address of the lane's fragment of (chunk 0, stage q, part 0, column tile t); everything
+            // else is a compile-time offset that fits the instruction's 16-bit field
+            unsigned vq[MT];
+            auto v_read = [&](int dq, int c, int t, uint4* v) {
+                const char* V = reinterpret_cast<const char*>(lds) + vq[t];
 #pragma unroll
-                for (int r = 0; r < NP; r++) v[r] = V[r * W::V_PART_U4];
+                for (int r = 0; r < NP; r++) v[r] = *reinterpret_cast<const uint4*>(V + (((c * 5 + dq) * NP + r) * W::V_PART_U4) * 16);
             };
-            // step nn = 3 c + t of stage q; nn >= 6: of the next stage (q == 4: a harmless re-read)
-            auto v_read_step = [&](int q, int nn, uint4* v) {
-                if (nn >= 2 * MT) v_read(q < 4 ? q + 1 : 4, (nn - 2 * MT) / MT, (nn - 2 * MT) % MT, v);
-                else v_read(q, nn / MT, nn % MT, v);
+            // step nn = 3 c + t of the stage; nn >= 6: of the next stage (after the row's last: a harmless read of chunk 1)
+            auto v_read_step = [&](int nn, uint4* v) {
+                if (nn >= 2 * MT) v_read(1, (nn - 2 * MT) / MT, (nn - 2 * MT) % MT, v);
+                else v_read(0, nn / MT, nn % MT, v);
             };
             uint4 vf[RING][NP];                                     // (kept as plain words: a bf16 vector across a branch is re-packed element-wise)
 #pragma unroll
-            for (int a = 0; a < AH; a++) v_read_step(0, a, vf[a]);
+            for (int t = 0; t < MT; t++) vq[t] = vaddr[t];
+#pragma unroll
+            for (int a = 0; a < AH; a++) v_read_step(a, vf[a]);
 #pragma unroll 1
             for (int q = 0; q < 5; q++) {
                 f32x4 m[MT];
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
 #pragma unroll
                             for (int r = 0; r < NP; r++) vf[(n + AH) % RING][r] = vf[n % RING][r];
                         }
-                        else v_read_step(q, n + AH, vf[(n + AH) % RING]);
+                        else v_read_step(n + AH, vf[(n + AH) % RING]);
                         // the reads go out before the step's first MFMA, not (as the scheduler would have it, to shorten live
                         // ranges) before its last
                         if constexpr (NP == 2) __builtin_amdgcn_sched_barrier(0);
@@ -409,6 +425,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
                             }
                     }
                 }
+#pragma unroll
+                for (int t = 0; t < MT; t++) vq[t] += NP * W::V_PART_U4 * 16;
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();                                   // every wave has read this row of V
@@ -509,7 +527,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
     }
     // next convolution of the launch: swap the buffers, step the weights
     if (k & 1) { in = x; out = y; resid = resid0; } else { in = y; out = x; resid = x; }
-    wsrc += (size_t)100 * 8 * 64 * NP;
+    wconv += (size_t)100 * 8 * 64 * NP;
+    wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wconv), 0, W_CONV_BYTES, 0x00020000);
     }
 }
 
