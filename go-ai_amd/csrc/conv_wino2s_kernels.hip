@@ -177,12 +177,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
 
     // weights of a stage: the three bf16 parts of U[stage = (chunk * 4 + p) * 4 + q] in the lanes' own order:
     // lane (li, lq) gets output channel 16 wave + li, input channels 8 lq .. 8 lq + 7 of the chunk
-    const uint4* wsrc = wt + wave * (64 * NP) + lane; // [stage][wave][part][lane] x 16 B
+    // [stage][wave][part][lane] x 16 B as buffer loads: descriptor = the convolution's image, scalar offset = the stage,
+    // vector offset = the lane's place in the stage -- no address arithmetic in the loop
+    constexpr unsigned W_STAGE_BYTES = 8 * 64 * NP * 16;
+    const unsigned wlane = (wave * (64 * NP) + lane) * 16;
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wt), 0, 64 * W_STAGE_BYTES, 0x00020000);
     u32x4 wf[2][NP];
     auto load_b = [&](int stage, u32x4* b) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(wsrc + (size_t)stage * (8 * 64 * NP));
 #pragma unroll
-        for (int r = 0; r < NP; r++) b[r] = src[64 * r];
+        for (int r = 0; r < NP; r++)
+            b[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024 * r, stage * W_STAGE_BYTES, 0));
         // keep the load where it is written (the optimiser would sink it to the loop's end, in front of its use;
         // wt is deliberately not __restrict__: loads from a noalias pointer may cross this fence)
         asm volatile("" ::: "memory");

@@ -455,6 +455,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
         // also leave their cells in the image regions (dead since the last transform), so the next convolution starts
         // without a trip through memory.  lcell = the wtile's cell (0, 0) within the workgroup's boards.
         const bool to_lds = NP == 2 && wave < 4 && k + 1 < n_convs;
+        // ... and when this is the first convolution of a residual block (even k), whose output only the next convolution
+        // reads (the block's second convolution adds the block's INPUT), those cells need not go to memory at all
+        const bool to_mem = !(to_lds && (k & 1) == 0);
         f32x4* img_next = Img + (wave >> 1) * W::IMG_CH_U4 + 16 + (wave & 1) * 4 + lq;
         auto tile = [&](const f32x4 (&yv)[3][3], const f32x4 bv, long base, bool on, int board_l, int group_lanes, int lcell) {
             // base = element offset of output (0, 0) of the wtile, this lane's channels
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
                     if (R) v += rv[i][j];
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
-                    *reinterpret_cast<f32x4*>(&out[base + (i * S + j) * 128]) = v;
+                    if (to_mem) *reinterpret_cast<f32x4*>(&out[base + (i * S + j) * 128]) = v;
                     if constexpr (NP == 2) {
                         mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
                         if (to_lds) img_next[(lcell + i * S + j) * 8] = v;
