@@ -231,9 +231,10 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--games", type=int, default=0, help="games per GPU (default: the config's)")
     ap.add_argument("--dtype", choices=["auto", "f32", "bf16x3", "bf16x6", "f16x3"], default="auto",
-                    help="arithmetic of the trunk convolutions.  auto = bf16x6 (bf16 matrix cores on operands split exactly "
-                         "into three bf16 parts: fp32-grade results, error at the exact-fp32 Winograd kernels' own level); "
-                         "f32 = exact fp32 MFMA everywhere; bf16x3 = two-part split (1e-5 class, opt-in)")
+                    help="arithmetic of the trunk convolutions.  auto = f16x3 (fp16 matrix cores on operands split into two "
+                         "fp16 parts and scaled by exact powers of two per board: fp32-grade results, error at the exact-fp32 "
+                         "Winograd kernels' own level); bf16x6 = the same kernels with three bf16 parts and six products; "
+                         "f32 = exact fp32 MFMA everywhere; bf16x3 = two-part bf16 split (1e-5 class, opt-in)")
     ap.add_argument("--groups", type=int, default=1, help="independent game groups on separate HIP streams")
     ap.add_argument("--no-refill", action="store_true",
                     help="leave the slot of a finished game idle instead of starting the next game in it")
@@ -250,7 +251,7 @@ def main():
     if args.warmup < 0:
         args.warmup = 5 if args.config == "c2" else 1
     if args.dtype == "auto":
-        args.dtype = "bf16x6"
+        args.dtype = "f16x3"
     global SIZE, SIMS, LAYERS
     SIZE, SIMS, LAYERS = cfg["size"], cfg["sims"], cfg["layers"]
 

@@ -293,15 +293,17 @@ def test_c4_sampled_games_match_sequential_oracle(full_c4):
 
 
 # =================================================================================================
-# The arithmetic bench.py runs by default since round 2: GOAI_DTYPE_BF16X6 (Winograd products on the bf16 matrix
-# cores, three-way split operands).  Same properties at C2's and C4's full sizes, and sampled games replayed by
-# the sequential oracle fed the bf16x6 network's own logits: the search is bit-exact whatever produced the logits.
+# The arithmetic bench.py runs by default: GOAI_DTYPE_F16X3 (Winograd products on the fp16 matrix cores, two-way
+# split operands scaled per board), and round 2's earlier GOAI_DTYPE_BF16X6 (bf16, three-way split).  Same properties
+# at C2's and C4's full sizes, and sampled games replayed by the sequential oracle fed the network's own logits: the
+# search is bit-exact whatever produced the logits; halves of the batch searched alone give bit-identical results
+# (a board's activation scale depends on that board alone).
 # =================================================================================================
-def _search_x6(size, games, sims, roots, offset=0, max_batch=None):
+def _search_x6(size, games, sims, roots, offset=0, max_batch=None, dtype="f16x3"):
     from go_ai.engine import Context
     from go_ai.models import random_state_dict
     c = Context(size)
-    c.nn_init(Context.NET_AC, 3, max_batch or games, dtype=Context.DTYPE_BF16X6)
+    c.nn_init(Context.NET_AC, 3, max_batch or games, dtype=Context.DTYPE_F16X3 if dtype == "f16x3" else Context.DTYPE_BF16X6)
     c.load_weights(random_state_dict("ac", size, 0, 3))
     c.mcts_init(games, sims)
     c.mcts_reset(roots)
@@ -313,12 +315,15 @@ def _search_x6(size, games, sims, roots, offset=0, max_batch=None):
     return c, visits, prior, root_visits, pi.cpu().numpy(), acts, cnt
 
 
-@pytest.mark.parametrize("size,games,sims,random_moves,step", [(9, 1024, 81, 40, 128), (13, 8192, 81, 80, 2048)])
-def test_bf16x6_full_config_search(size, games, sims, random_moves, step):
+@pytest.mark.parametrize("size,games,sims,random_moves,step,dtype", [
+    (9, 1024, 81, 40, 128, "f16x3"), (9, 1024, 81, 40, 256, "bf16x6"), (13, 8192, 81, 80, 2048, "f16x3")])
+def test_split_dtype_full_config_search(size, games, sims, random_moves, step, dtype):
     from go_ai.engine import Context
     roots = _roots_of(size, games, sims, random_moves, "ac")
-    c, visits, prior, root_visits, pi, acts, cnt = _search_x6(size, games, sims, roots)
-    assert c.nn_conv_algo() == (Context.CONV_WINOGRAD_F3_BF16X6 if size == 9 else Context.CONV_WINOGRAD_BF16X6)
+    c, visits, prior, root_visits, pi, acts, cnt = _search_x6(size, games, sims, roots, dtype=dtype)
+    assert c.nn_conv_algo() == {("f16x3", True): Context.CONV_WINOGRAD_F3_F16X3, ("f16x3", False): Context.CONV_WINOGRAD_F16X3,
+                                ("bf16x6", True): Context.CONV_WINOGRAD_F3_BF16X6,
+                                ("bf16x6", False): Context.CONV_WINOGRAD_BF16X6}[(dtype, size == 9)]
     assert cnt["errors"] == 0 and cnt["leaf_evals"] == games * (sims + 1)
     st = roots.cpu().numpy()
     valid = _valid_of(st)
@@ -343,6 +348,6 @@ def test_bf16x6_full_config_search(size, games, sims, random_moves, step):
     # two shards of half the games (what two GPUs would own): bit-identical searches and draws
     half = games // 2
     for lo in (0, half):
-        c2, v, p, _, q, a, _ = _search_x6(size, half, sims, roots[lo:lo + half], offset=lo, max_batch=games)
+        c2, v, p, _, q, a, _ = _search_x6(size, half, sims, roots[lo:lo + half], offset=lo, max_batch=games, dtype=dtype)
         c2.close()
         assert np.array_equal(v, visits[lo:lo + half]) and np.array_equal(q, pi[lo:lo + half]) and np.array_equal(a, acts[lo:lo + half])
