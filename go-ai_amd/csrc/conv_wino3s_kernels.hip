@@ -112,7 +112,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
                                                         const uint4* wt_all,
                                                         const float* __restrict__ bias_all,
                                                         const uint4* __restrict__ tab_g, int nboards, int n_convs,
-                                                        const int* __restrict__ wexp_all, float* amax_io, float amax_first)
+                                                        const int* __restrict__ wexp_all, float* amax_io, float amax_first,
+                                                        const float* __restrict__ head_w, const float* __restrict__ head_b,
+                                                        float* __restrict__ head_out)
 {
     using W = Wino3S<S, NP>;
     constexpr int P = W::P, MT = W::MT;
@@ -453,17 +455,29 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
     // choice is made once, not per cell (conv_wino3p_kernels.hip).
     // NP == 2: the accumulators are scaled back by 2^-(input scale of the tile's board + weight scale) first, and
     // the largest value a lane stores per tile goes, reduced over the lanes that share the board, into Amax.
-    auto epilogue = [&](auto has_resid) {
+    // Where a cell goes is decided once per convolution, not per cell (EM, below): every variant is straight-line code.
+    auto epilogue = [&](auto has_resid, auto mode) {
         constexpr bool R = decltype(has_resid)::value;
+        constexpr int EM = decltype(mode)::value;        // 0: memory; 1: memory + LDS; 2: LDS only; 3: the heads' 1x1 convolutions
         const int wexp = NP == 2 ? wexp_all[k] : 0;
         unsigned* amax_out = Amax + 4 * ((k + 1) & 1);
         // NP == 2: waves 0..3 hold input channels 0..63 of the next convolution of the launch = its chunks 0 and 1: they
         // also leave their cells in the image regions (dead since the last transform), so the next convolution starts
         // without a trip through memory.  lcell = the wtile's cell (0, 0) within the workgroup's boards.
-        const bool to_lds = NP == 2 && wave < 4 && k + 1 < n_convs;
+        constexpr bool to_lds = EM == 1 || EM == 2;
         // ... and when this is the first convolution of a residual block (even k), whose output only the next convolution
         // reads (the block's second convolution adds the block's INPUT), those cells need not go to memory at all
-        const bool to_mem = !(to_lds && (k & 1) == 0);
+        // head_out != NULL: the launch's last convolution feeds the heads' three 1x1 convolutions (+ folded BN, ReLU;
+        // nn_groups.h) and nothing else, so they are formed here and only their 3 values per cell leave the workgroup:
+        // a lane's four channels times the three weight rows go to LDS (the image and V regions are dead), one slot per
+        // (wave, lq), and are summed over the 32 slots in a fixed order below.
+        constexpr bool to_heads = EM == 3, to_mem = EM < 2;
+        f32x4 hwv[3];
+        if (to_heads) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) hwv[c] = *reinterpret_cast<const f32x4*>(&head_w[c * 128 + col]);
+        }
+        float* hp = reinterpret_cast<float*>(lds) + (size_t)((wave * 4 + lq) * (W::NBW * P)) * 3;
         f32x4* img_next = Img + (wave >> 1) * W::IMG_CH_U4 + 16 + (wave & 1) * 4 + lq;
         auto tile = [&](const f32x4 (&yv)[3][3], const f32x4 bv, long base, bool on, int board_l, int group_lanes, int lcell) {
             // base = element offset of output (0, 0) of the wtile, this lane's channels
@@ -494,6 +508,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
                     if constexpr (NP == 2) {
                         mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
                         if (to_lds) img_next[(lcell + i * S + j) * 8] = v;
+                    }
+                    if (to_heads) {
+#pragma unroll
+                        for (int c = 0; c < 3; c++)
+                            hp[(lcell + i * S + j) * 3 + c] = fmaf(v[3], hwv[c][3], fmaf(v[2], hwv[c][2], fmaf(v[1], hwv[c][1], v[0] * hwv[c][0])));
                     }
                 }
             }
@@ -527,8 +546,30 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
             for (int j = 0; j < 3; j++) yv[i][j] = Y[i][j][2];
         tile(yv, bv, (board2 * P + 6 * S + 6) * 128 + col, li < 4 && board2 < nboards, li & 3, 1, (li & 3) * P + 6 * S + 6);   // wtile 8 = (ty, tx) = (2, 2)
     };
-    if (resid) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
+    {
+        const bool lds_next = NP == 2 && wave < 4 && k + 1 < n_convs;
+        const int em = (head_out != nullptr && k == n_convs - 1) ? 3 : !lds_next ? 0 : (k & 1) ? 1 : 2;
+        auto with_mode = [&](auto has_resid) {
+            if (em == 0) epilogue(has_resid, std::integral_constant<int, 0>{});
+            else if (em == 1) epilogue(has_resid, std::integral_constant<int, 1>{});
+            else if (em == 2) epilogue(has_resid, std::integral_constant<int, 2>{});
+            else epilogue(has_resid, std::integral_constant<int, 3>{});
+        };
+        if (resid) with_mode(std::true_type{});
+        else with_mode(std::false_type{});
+    }
+    if (head_out != nullptr && k == n_convs - 1) {
+        __syncthreads();
+        const float* hs = reinterpret_cast<const float*>(lds);
+        for (int o = tid; o < W::NBW * P * 3; o += 512) {
+            const int cell = o / 3, c = o - 3 * cell, board = cell / P;
+            float sum = 0.0f;
+#pragma unroll 8
+            for (int sl = 0; sl < 32; sl++) sum += hs[(size_t)sl * (W::NBW * P * 3) + o];
+            if (b_first + board < nboards)
+                head_out[((size_t)(b_first + board) * 3 + c) * P + (cell - board * P)] = fmaxf(sum + head_b[c], 0.0f);
+        }
+    }
     W3S_STAMP(22);
     if (NP == 2 && k == n_convs - 1 && amax_io) {
         __syncthreads();
@@ -565,9 +606,11 @@ size_t wino3s_build_table(int S_rt, uint16_t* out)
 // Any number of boards (4 per workgroup, as many rounds of workgroups as it takes).
 // parts = 3: bf16; parts = 2: fp16, which also takes wexp[n_convs] (the weights' scale exponents) and the bound of the
 // first convolution's input, amax_first > 0 or amax_io[nboards]; amax_io (may be NULL) receives the output's bounds.
+// head_out != NULL: instead of the last convolution's output, the launch stores head_out[board][3][P] = ReLU(the three
+// 1x1 head convolutions head_w[3][128], head_b[3] of it) -- what launch_heads takes with act_is_h.
 int launch_conv3x3_wino3s(int S_rt, float* x, float* y, const float* resid0, const void* wt_split, const float* bias,
                           const void* tab, int nboards, int n_convs, hipStream_t st, int parts, const int* wexp,
-                          float* amax_io, float amax_first)
+                          float* amax_io, float amax_first, const float* head_w, const float* head_b, float* head_out)
 {
     if (S_rt != 9 || nboards < 1) {
         set_error("the split F(3x3,3x3) convolution runs 9x9 boards");
@@ -584,11 +627,11 @@ int launch_conv3x3_wino3s(int S_rt, float* x, float* y, const float* resid0, con
     if (parts == 2)
         k_conv3x3_wino3s<9, 2><<<dim3((nboards + 3) / 4), dim3(512), 0, st>>>(x, y, resid0, reinterpret_cast<const uint4*>(wt_split), bias,
                                                                               reinterpret_cast<const uint4*>(tab), nboards, n_convs,
-                                                                              wexp, amax_io, amax_first);
+                                                                              wexp, amax_io, amax_first, head_w, head_b, head_out);
     else
         k_conv3x3_wino3s<9, 3><<<dim3((nboards + 3) / 4), dim3(512), 0, st>>>(x, y, resid0, reinterpret_cast<const uint4*>(wt_split), bias,
                                                                               reinterpret_cast<const uint4*>(tab), nboards, n_convs,
-                                                                              nullptr, nullptr, 0.0f);
+                                                                              nullptr, nullptr, 0.0f, head_w, head_b, head_out);
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }

@@ -52,8 +52,8 @@ int nn_init(goai_ctx* c, int kind, int layers, int max_batch, int dtype);
 int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* tensors, const int64_t* numels, int n);
 int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, int n);
 int nn_piece_conv0(goai_ctx* c, const uint8_t* states, int n);
-int nn_piece_trunk(goai_ctx* c, int n, float** out);
-int nn_piece_heads(goai_ctx* c, const float* x, float* pi, float* val, int n);
+int nn_piece_trunk(goai_ctx* c, int n, float** out, bool* out_is_h);
+int nn_piece_heads(goai_ctx* c, const float* x, bool x_is_h, float* pi, float* val, int n);
 int nn_static_setup(int device);   // once per device, with that device current (goai_ctx_create)
 int nn_forward_static(goai_ctx* c, const uint8_t* states, float* pi, float* val, int n);
 

@@ -209,18 +209,19 @@ int mcts_steps(goai_ctx* c, int n_steps)
     const bool small_batch = t.n_active <= 6 * c->net.n_cu;
     if (!no_fusion && small_batch && n_steps >= 2 && !t.pending_select && t.n_active <= c->net.max_batch && c->net.w0_split) {
         float* x = nullptr;
+        bool x_is_h = false;                    // x = the heads' 1x1 convolutions, formed by the trunk launch (nn_host.hip)
         if ((rc = mcts_select(c, nullptr))) return rc;
         if ((rc = nn_piece_conv0(c, t.leaf_planes, t.n_active))) return rc;
         for (int s = 0; s < n_steps; s++) {
-            if ((rc = nn_piece_trunk(c, t.n_active, &x))) return rc;
+            if ((rc = nn_piece_trunk(c, t.n_active, &x, &x_is_h))) return rc;
             if (s + 1 < n_steps) {
                 if ((rc = launch_post_forward(c->S, t, x, c->net.hw, c->net.w0_split, c->net.b0, c->net.shift, c->net.act[0],
-                                              c->stream)))
+                                              c->stream, x_is_h)))
                     return rc;
                 t.steps_since_reset++;          // that step's backup and the next step's select are in the stream
             }
         }
-        if ((rc = nn_piece_heads(c, x, t.pi_logits, t.val_logits, t.n_active))) return rc;
+        if ((rc = nn_piece_heads(c, x, x_is_h, t.pi_logits, t.val_logits, t.n_active))) return rc;
         return mcts_backup(c, t.pi_logits, nullptr, t.val_logits, 1);
     }
     for (int s = 0; s < n_steps; s++) {

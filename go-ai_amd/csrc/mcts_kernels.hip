@@ -376,14 +376,14 @@ extern "C" int goai_debug_pf_stamps(unsigned long long* host_out, int n)
 
 template <int S>
 __global__ __launch_bounds__(256) void k_post_forward(Tree t, const float* act, HeadWeights hw, const uint4* __restrict__ w0s,
-                                                      const float* __restrict__ b0, float shift, float* act0)
+                                                      const float* __restrict__ b0, float shift, float* act0, bool act_is_h)
 {
     static_assert(HB == 2 && NB0 == 2, "two games per workgroup");
     __shared__ HeadsLds<S> hl;
     __shared__ Conv0Lds<S> cl;
     const int n = t.n_active, b_first = blockIdx.x * 2, wave = threadIdx.x >> 6;
     PF_STAMP(0);
-    heads_groups<S>(hl, act, hw, 1, t.pi_logits, t.val_logits, n, b_first, n);          // one group: b_first, b_first + 1
+    heads_groups<S>(hl, act, hw, 1, t.pi_logits, t.val_logits, n, b_first, n, act_is_h);   // one group: b_first, b_first + 1
     // (workgroup-scope ordering is all that is needed: every datum handed from phase to phase stays inside the
     // workgroup, whose waves share the CU's L1; a device-scope fence would write the XCD's whole dirty L2 back)
     __threadfence_block();
@@ -926,10 +926,10 @@ __global__ __launch_bounds__(64) void k_mcts_export(Tree t, int g, int32_t* __re
 int launch_mcts_reset(int S_rt, const Tree& t, const uint8_t* roots, hipStream_t st) { LAUNCH_PER_GAME(k_mcts_reset, t, roots); }
 int launch_mcts_select(int S_rt, const Tree& t, uint8_t* leaf_out, hipStream_t st) { LAUNCH_PER_GAME(k_mcts_select, t, leaf_out); }
 int launch_post_forward(int S_rt, const Tree& t, const float* act, const HeadWeights& hw, const void* w0_split, const float* b0,
-                        float shift, float* act0, hipStream_t st)
+                        float shift, float* act0, hipStream_t st, bool act_is_h)
 {
     const int grid = (t.n_active + 1) / 2;
-    GOAI_DISPATCH_SIZE(S_rt, k_post_forward<S><<<dim3(grid), dim3(256), 0, st>>>(t, act, hw, (const uint4*)w0_split, b0, shift, act0));
+    GOAI_DISPATCH_SIZE(S_rt, k_post_forward<S><<<dim3(grid), dim3(256), 0, st>>>(t, act, hw, (const uint4*)w0_split, b0, shift, act0, act_is_h));
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }

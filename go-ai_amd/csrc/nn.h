@@ -49,6 +49,8 @@ struct Net {
     float* head_blob = nullptr;
     HeadWeights hw{};
     float* act[3] = { nullptr, nullptr, nullptr };   // activation buffers [max_batch*P][128]
+    float* hbuf = nullptr;     // heads_in_trunk: [max_batch][3][P], the heads' 1x1 convolutions as left by the trunk launch
+    bool heads_in_trunk = false;   // split F(3x3,3x3) trunk in one launch: its last epilogue forms the heads' 1x1 convolutions
 };
 
 // GOAI_DTYPE_F16X3 (conv_wino3s_kernels.hip): exponent of the power of two that scales a board's input activations, all
@@ -87,14 +89,17 @@ int launch_conv3x3_wino3p(int S, float* x, float* y, const float* resid0, const 
 size_t wino3s_build_table(int S, uint16_t* out);
 int launch_conv3x3_wino3s(int S, float* x, float* y, const float* resid0, const void* wt_split, const float* bias,
                           const void* tab, int nboards, int n_convs, hipStream_t st, int parts = 3, const int* wexp = nullptr,
-                          float* amax_io = nullptr, float amax_first = 0.0f);
+                          float* amax_io = nullptr, float amax_first = 0.0f, const float* head_w = nullptr,
+                          const float* head_b = nullptr, float* head_out = nullptr);
 int launch_conv3x3_wino2s(int S, const float* in, const void* wt_split, const float* bias, const float* resid, float* out,
                           int nboards, hipStream_t st, int parts = 3, int wexp = 0, float* amax_io = nullptr,
                           float amax_first = 0.0f);
 int launch_conv3x3_wino(int S, const float* in, const float* wt_wino, const float* bias, const float* resid, float* out,
                         int nboards, hipStream_t st);
+// act_is_h: `act` is not the trunk's output [board][P][128] but the heads' 1x1 convolutions of it, [board][3][P]
+// (formed by the trunk launch itself: launch_conv3x3_wino3s with head_out)
 int launch_heads(int S, const float* act, const HeadWeights& hw, int is_ac, float* pi, float* val, int nboards,
-                 hipStream_t st);
+                 hipStream_t st, bool act_is_h = false);
 int launch_numpy_shim(int S, const uint8_t* states, float* pi, float* val, int n, hipStream_t st);
 
 }  // namespace goai

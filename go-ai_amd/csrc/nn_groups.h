@@ -125,11 +125,13 @@ struct HeadsLds {
     float z[HB][4];
 };
 
-// groups of HB boards starting at b_begin, then every b_stride boards, by one 256-thread workgroup (all threads call it)
+// groups of HB boards starting at b_begin, then every b_stride boards, by one 256-thread workgroup (all threads call it).
+// act_is_h: `act` holds the 1x1 convolutions already, [board][3][P] (the split F(3x3,3x3) trunk forms them in its last
+// epilogue), and they are only copied into LDS.
 template <int S>
 __device__ __forceinline__ void heads_groups(HeadsLds<S>& lds, const float* __restrict__ act, const HeadWeights& hw, int is_ac,
                                              float* __restrict__ pi_out, float* __restrict__ val_out, int nboards, int b_begin,
-                                             int b_stride)
+                                             int b_stride, bool act_is_h = false)
 {
     using G = Geom<S>;
     constexpr int JG = HeadsLds<S>::JG;
@@ -155,7 +157,9 @@ __device__ __forceinline__ void heads_groups(HeadsLds<S>& lds, const float* __re
         // ---- 1x1 convolutions -> h ----
         // All of a thread's activation loads (64 B per item, up to NLD items in flight) are issued before the first
         // multiply: issued inside the loop they were one L2 round trip per iteration (6 of them at 9x9).
-        const int items = nb * G::P * 8;
+        const int items = act_is_h ? 0 : nb * G::P * 8;
+        if (act_is_h)
+            for (int i = tid; i < nb * 3 * G::P; i += 256) (&h[0][0])[i] = act[(size_t)b0 * 3 * G::P + i];
         constexpr int NIT = (HB * G::P * 8 + 255) / 256, NLD = NIT < 6 ? NIT : 6;
         for (int it0 = 0; it0 < items; it0 += 256 * NLD) {
             f32x4 xs[NLD][4];

@@ -155,6 +155,10 @@ static int nn_init_impl(goai_ctx* c, int kind, int layers, int max_batch, int dt
     if ((rc = dev_alloc(c, (void**)&n.head_blob, head_floats * sizeof(float)))) return rc;
     for (int i = 0; i < 3; i++)
         if ((rc = dev_alloc(c, (void**)&n.act[i], (size_t)max_batch * P * 128 * sizeof(float)))) return rc;
+    // The split F(3x3,3x3) trunk in one launch ends with the heads' three 1x1 convolutions (conv_wino3s_kernels.hip): its
+    // last convolution's 128 channels never go to memory.  GOAI_NO_HEAD_FUSION=1: the heads do them, as everywhere else.
+    n.heads_in_trunk = layers > 0 && n.split6 && n.wino_mode == 3 && n.trunk_fused && !getenv("GOAI_NO_HEAD_FUSION");
+    if (n.heads_in_trunk && (rc = dev_alloc(c, (void**)&n.hbuf, (size_t)max_batch * 3 * P * sizeof(float)))) return rc;
     return GOAI_OK;
 }
 
@@ -487,8 +491,10 @@ static int timed_conv(goai_ctx* c, const float* in, int l, const float* b, const
 // when the context's profile is on (creates events, so not for the allocation-free entry point).
 // The residual trunk over the nb boards whose first-layer activations are in act[0]; *out = the buffer (one of the
 // three) that holds the result.
-static int nn_trunk_on(goai_ctx* c, float* const act[3], int nb, bool prof, float** out)
+// *out_is_h: *out is not an activation buffer but net.hbuf, the heads' 1x1 convolutions (Net::heads_in_trunk)
+static int nn_trunk_on(goai_ctx* c, float* const act[3], int nb, bool prof, float** out, bool* out_is_h)
 {
+    *out_is_h = false;
     Net& net = c->net;
     const int M = nb * c->P;
     int rc;
@@ -505,7 +511,8 @@ static int nn_trunk_on(goai_ctx* c, float* const act[3], int nb, bool prof, floa
         }
         rc = net.split6
                  ? launch_conv3x3_wino3s(c->S, x, y, nullptr, net.wt_split6, net.bt, net.wino3p_tab, nb, 2 * net.layers, c->stream,
-                                         net.parts, net.wexp, nullptr, net.amax0)
+                                         net.parts, net.wexp, nullptr, net.amax0, net.heads_in_trunk ? net.hw.conv_w : nullptr,
+                                         net.hw.conv_b, net.heads_in_trunk ? net.hbuf : nullptr)
              : net.wino3_paired
                  ? launch_conv3x3_wino3p(c->S, x, y, nullptr, net.wt_wino3, net.bt, net.wino3p_tab, nb, net.n_cu,
                                          2 * net.layers, c->stream)
@@ -513,6 +520,11 @@ static int nn_trunk_on(goai_ctx* c, float* const act[3], int nb, bool prof, floa
                                         2 * net.layers, c->stream);
         if (e1) GOAI_HIP_CHECK(hipEventRecord(e1, c->stream));
         if (rc) return rc;
+        if (net.heads_in_trunk) {
+            *out = net.hbuf;
+            *out_is_h = true;
+            return GOAI_OK;
+        }
     } else
     for (int l = 0; l < net.layers; l++) {
         if (prof) {
@@ -542,9 +554,10 @@ static int nn_forward_on(goai_ctx* c, float* const act[3], int cap, bool timed, 
         if ((rc = launch_conv0(c->S, states + (size_t)done * 6 * P, net.w0, net.w0_split, net.b0, net.shift, act[0], nb, c->stream)))
             return rc;
         float* x = nullptr;
-        if ((rc = nn_trunk_on(c, act, nb, prof, &x))) return rc;
+        bool x_is_h = false;
+        if ((rc = nn_trunk_on(c, act, nb, prof, &x, &x_is_h))) return rc;
         if ((rc = launch_heads(c->S, x, net.hw, net.kind == 0 && pi != nullptr, pi ? pi + (size_t)done * A : nullptr, val + done, nb,
-                               c->stream)))
+                               c->stream, x_is_h)))
             return rc;
     }
     return GOAI_OK;
@@ -557,10 +570,13 @@ int nn_piece_conv0(goai_ctx* c, const uint8_t* states, int n)
     Net& net = c->net;
     return launch_conv0(c->S, states, net.w0, net.w0_split, net.b0, net.shift, net.act[0], n, c->stream);
 }
-int nn_piece_trunk(goai_ctx* c, int n, float** out) { return nn_trunk_on(c, c->net.act, n, c->prof_enabled, out); }
-int nn_piece_heads(goai_ctx* c, const float* x, float* pi, float* val, int n)
+int nn_piece_trunk(goai_ctx* c, int n, float** out, bool* out_is_h)
 {
-    return launch_heads(c->S, x, c->net.hw, c->net.kind == 0 && pi != nullptr, pi, val, n, c->stream);
+    return nn_trunk_on(c, c->net.act, n, c->prof_enabled, out, out_is_h);
+}
+int nn_piece_heads(goai_ctx* c, const float* x, bool x_is_h, float* pi, float* val, int n)
+{
+    return launch_heads(c->S, x, c->net.hw, c->net.kind == 0 && pi != nullptr, pi, val, n, c->stream, x_is_h);
 }
 
 int nn_forward_raw(goai_ctx* c, const uint8_t* states, float* pi, float* val, int n)

@@ -76,10 +76,10 @@ __global__ __launch_bounds__(256) void k_conv0_mfma(const uint8_t* __restrict__ 
 
 template <int S>
 __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ act, HeadWeights hw, int is_ac,
-                                               float* __restrict__ pi_out, float* __restrict__ val_out, int nboards)
+                                               float* __restrict__ pi_out, float* __restrict__ val_out, int nboards, bool act_is_h)
 {
     __shared__ HeadsLds<S> lds;
-    heads_groups<S>(lds, act, hw, is_ac, pi_out, val_out, nboards, blockIdx.x * HB, gridDim.x * HB);
+    heads_groups<S>(lds, act, hw, is_ac, pi_out, val_out, nboards, blockIdx.x * HB, gridDim.x * HB, act_is_h);
 }
 
 // --------------------------------------------------------------------------------------
@@ -160,11 +160,11 @@ int launch_conv0(int S_rt, const uint8_t* states, const float* w0, const void* w
 }
 
 int launch_heads(int S_rt, const float* act, const HeadWeights& hw, int is_ac, float* pi, float* val, int nboards,
-                 hipStream_t st)
+                 hipStream_t st, bool act_is_h)
 {
     int groups = (nboards + HB - 1) / HB;
     int grid = groups < 8192 ? groups : 8192;
-    GOAI_DISPATCH_SIZE(S_rt, k_heads<S><<<dim3(grid), dim3(256), 0, st>>>(act, hw, is_ac, pi, val, nboards));
+    GOAI_DISPATCH_SIZE(S_rt, k_heads<S><<<dim3(grid), dim3(256), 0, st>>>(act, hw, is_ac, pi, val, nboards, act_is_h));
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }
