@@ -131,6 +131,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
     const float* resid = resid0;
     float* out = y;
 
+    // All workgroups reach their memory phases (epilogue stores, residual and image loads: 85 MB per convolution) at the same
+    // microsecond and wait for one another's bytes.  Starting them in W3S_GROUPS groups, W3S_SKEW x 64 cycles apart, spreads
+    // those phases (measured, six-convolution launch of 1024 boards: 336 us -> 328 us with 4 groups 3.9 us apart, the 12 us
+    // the last group starts late included; profiles/r02_wino3s_ablation.txt).  Only launches of several convolutions.
+#ifndef W3S_SKEW
+#define W3S_SKEW 127
+#define W3S_GROUPS 4
+#endif
+#ifndef W3S_REPS
+#define W3S_REPS 1
+#endif
+    if (n_convs > 1)
+        for (int i = ((blockIdx.x >> 3) % W3S_GROUPS) * W3S_REPS; i > 0; i--) __builtin_amdgcn_s_sleep(W3S_SKEW);
     for (int i = tid; i < W::V_U4; i += 512) Vs[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };   // the zero rows stay zero
     if (tid < 32) Img[(tid >> 4) * W::IMG_CH_U4 + (tid & 15)] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };   // the zero cells of both regions
     for (int e = tid; e < W::TAB_U4; e += 512) Tab[e] = tab_g[e];
