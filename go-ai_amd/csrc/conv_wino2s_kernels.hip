@@ -45,7 +45,12 @@ struct Wino2S {
     static constexpr int TAB_U4 = WT * 2;                          // 16 x u16 LDS addresses per wtile
     static constexpr int NI = (NBW * P * 8 + 511) / 512;           // staged 16-byte pieces per thread per chunk
     static constexpr int AMAX_U4 = 8;                              // [2][16]: input / output bounds of the boards as fp32 bits (NP == 2)
-    static constexpr int LDS_U4 = IMG_U4 + V_U4 + TAB_U4 + AMAX_U4;
+    // HEADS: the heads' 1x1 convolutions of the output, [32 slots = (wave, lq)][NBW * P cells][3] fp32, over the dead image and V
+    static constexpr int HP_U4 = (32 * NBW * P * 3 * 4 + 15) / 16;
+    // (the bounds, which the epilogue still reads and collects, stay clear of it: they are the block's last 128 bytes)
+    static constexpr int WORK_U4 = IMG_U4 + V_U4 + TAB_U4 + AMAX_U4;
+    static constexpr int LDS_U4 = WORK_U4 > HP_U4 + AMAX_U4 ? WORK_U4 : HP_U4 + AMAX_U4;
+    static_assert(LDS_U4 * 16 <= 160 * 1024, "LDS budget");
     static_assert(NBW <= 16, "bounds table");
     static_assert(NBW >= 1, "board too large for one workgroup");
     static_assert(LDS_U4 * 16 <= 160 * 1024, "LDS budget");
@@ -58,11 +63,14 @@ __device__ __forceinline__ unsigned w2s_pack(unsigned a, unsigned b) { return __
 
 // NP == 2 only: wexp = the weights' scale exponent; amax_first > 0: bound of every board's input, else amax_io[board];
 // amax_io receives the bound of the output, per board.
-template <int S, bool RESID, int NP>
+// HEADS (the trunk's last convolution): instead of the output, out[board][3][P] = ReLU(the heads' three 1x1 convolutions
+// head_w[3][128], head_b[3] of it), formed as in conv_wino3s_kernels.hip: the output's 128 channels never go to memory.
+template <int S, bool RESID, int NP, bool HEADS>
 __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict__ in, const uint4* wt,
                                                         const float* __restrict__ bias,
                                                         const float* __restrict__ resid, float* __restrict__ out,
-                                                        int nboards, int wexp, float* amax_io, float amax_first)
+                                                        int nboards, int wexp, float* amax_io, float amax_first,
+                                                        const float* __restrict__ head_w, const float* __restrict__ head_b)
 {
     using W = Wino2S<S, NP>;
     constexpr int P = W::P, MT = W::MT;
@@ -70,7 +78,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     f32x4* Img = lds;
     f32x4* Vs = lds + W::IMG_U4;
     uint16_t* Tab = reinterpret_cast<uint16_t*>(lds + W::IMG_U4 + W::V_U4);
-    unsigned* amax_in = reinterpret_cast<unsigned*>(lds + W::IMG_U4 + W::V_U4 + W::TAB_U4);
+    unsigned* amax_in = reinterpret_cast<unsigned*>(lds + W::LDS_U4 - W::AMAX_U4);
     unsigned* amax_out = amax_in + 16;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -289,6 +297,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     // first cell instead: no branch around a load), so the loads' latency is paid once per group, not once per cell.
     const int col = wave * 16 + 4 * lq;
     const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col]);
+    f32x4 hwv[3];
+    float* hp = reinterpret_cast<float*>(lds) + (size_t)((wave * 4 + lq) * (W::NBW * P)) * 3;
+    if constexpr (HEADS) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) hwv[c] = *reinterpret_cast<const f32x4*>(&head_w[c * 128 + col]);
+        __syncthreads();                                     // every wave has read the last row of V: LDS is free
+    }
     constexpr int GT = 4;                                    // tiles per group: 16 loads in flight
 #pragma unroll
     for (int t0 = 0; t0 < MT; t0 += GT) {
@@ -331,7 +346,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
                 if (ok[g][ij]) {
-                    *reinterpret_cast<f32x4*>(&out[off[g][ij]]) = v;
+                    if constexpr (HEADS) {
+                        const int lcell = (int)(off[g][ij] >> 7) - b_first * P;      // (off = cell * 128 + col, col < 128)
+#pragma unroll
+                        for (int c = 0; c < 3; c++)
+                            hp[lcell * 3 + c] = fmaf(v[3], hwv[c][3], fmaf(v[2], hwv[c][2], fmaf(v[1], hwv[c][1], v[0] * hwv[c][0])));
+                    } else
+                        *reinterpret_cast<f32x4*>(&out[off[g][ij]]) = v;
                     if constexpr (NP == 2) mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
                 }
             }
@@ -343,22 +364,44 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
             }
         }
     }
-    if constexpr (NP == 2) {
+    if constexpr (NP == 2 && !HEADS) {
         __syncthreads();
         if (tid < W::NBW && b_first + tid < nboards) amax_io[b_first + tid] = __uint_as_float(amax_out[tid]);
+    }
+    if constexpr (HEADS) {
+        __syncthreads();
+        const float* hs = reinterpret_cast<const float*>(lds);
+        for (int o = tid; o < W::NBW * P * 3; o += 512) {
+            const int cell = o / 3, c = o - 3 * cell, board = cell / P;
+            float sum = 0.0f;
+#pragma unroll 8
+            for (int sl = 0; sl < 32; sl++) sum += hs[(size_t)sl * (W::NBW * P * 3) + o];
+            if (b_first + board < nboards)
+                out[((size_t)(b_first + board) * 3 + c) * P + (cell - board * P)] = fmaxf(sum + head_b[c], 0.0f);
+        }
     }
 }
 
 template <int S, int NP>
 static int launch_wino2s_size(const float* in, const void* wt_split, const float* bias, const float* resid, float* out,
-                              int nboards, hipStream_t st, int wexp, float* amax_io, float amax_first)
+                              int nboards, hipStream_t st, int wexp, float* amax_io, float amax_first, const float* head_w,
+                              const float* head_b)
 {
     const int grid = (nboards + Wino2S<S, NP>::NBW - 1) / Wino2S<S, NP>::NBW;
     const uint4* wt = reinterpret_cast<const uint4*>(wt_split);
-    if (resid)
-        k_conv3x3_wino2s<S, true, NP><<<dim3(grid), dim3(512), 0, st>>>(in, wt, bias, resid, out, nboards, wexp, amax_io, amax_first);
+    if (head_w && !resid) {
+        set_error("the heads' 1x1 convolutions are formed by a block's second convolution (with its residual)");
+        return GOAI_ERR_ARG;
+    }
+    if (head_w)
+        k_conv3x3_wino2s<S, true, NP, true><<<dim3(grid), dim3(512), 0, st>>>(in, wt, bias, resid, out, nboards, wexp, amax_io, amax_first,
+                                                                              head_w, head_b);
+    else if (resid)
+        k_conv3x3_wino2s<S, true, NP, false><<<dim3(grid), dim3(512), 0, st>>>(in, wt, bias, resid, out, nboards, wexp, amax_io, amax_first,
+                                                                               nullptr, nullptr);
     else
-        k_conv3x3_wino2s<S, false, NP><<<dim3(grid), dim3(512), 0, st>>>(in, wt, bias, resid, out, nboards, wexp, amax_io, amax_first);
+        k_conv3x3_wino2s<S, false, NP, false><<<dim3(grid), dim3(512), 0, st>>>(in, wt, bias, resid, out, nboards, wexp, amax_io, amax_first,
+                                                                                nullptr, nullptr);
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }
@@ -366,18 +409,20 @@ static int launch_wino2s_size(const float* in, const void* wt_split, const float
 // wt_split: [64 stages][8 waves][parts][64 lanes][8 x 16 bit] of one convolution (nn_host.hip).
 // parts = 3: bf16; parts = 2: fp16, which also takes the weights' scale exponent wexp and the boards' bounds
 // amax_io[nboards] (read unless amax_first > 0 bounds every board's input; always written).
+// head_w != NULL: `out` receives [board][3][P] = the heads' 1x1 convolutions of the output (see the kernel) instead of it.
 int launch_conv3x3_wino2s(int S_rt, const float* in, const void* wt_split, const float* bias, const float* resid,
-                          float* out, int nboards, hipStream_t st, int parts, int wexp, float* amax_io, float amax_first)
+                          float* out, int nboards, hipStream_t st, int parts, int wexp, float* amax_io, float amax_first,
+                          const float* head_w, const float* head_b)
 {
     if (parts == 2) {
         if (!amax_io) {
             set_error("the fp16 F(2x2,3x3) convolution needs the boards' bounds (amax_io)");
             return GOAI_ERR_ARG;
         }
-        GOAI_DISPATCH_SIZE(S_rt, return (launch_wino2s_size<S, 2>(in, wt_split, bias, resid, out, nboards, st, wexp, amax_io, amax_first)));
+        GOAI_DISPATCH_SIZE(S_rt, return (launch_wino2s_size<S, 2>(in, wt_split, bias, resid, out, nboards, st, wexp, amax_io, amax_first, head_w, head_b)));
         return GOAI_OK;
     }
-    GOAI_DISPATCH_SIZE(S_rt, return (launch_wino2s_size<S, 3>(in, wt_split, bias, resid, out, nboards, st, 0, nullptr, 0.0f)));
+    GOAI_DISPATCH_SIZE(S_rt, return (launch_wino2s_size<S, 3>(in, wt_split, bias, resid, out, nboards, st, 0, nullptr, 0.0f, head_w, head_b)));
     return GOAI_OK;
 }
 

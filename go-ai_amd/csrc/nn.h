@@ -93,7 +93,7 @@ int launch_conv3x3_wino3s(int S, float* x, float* y, const float* resid0, const 
                           const float* head_b = nullptr, float* head_out = nullptr);
 int launch_conv3x3_wino2s(int S, const float* in, const void* wt_split, const float* bias, const float* resid, float* out,
                           int nboards, hipStream_t st, int parts = 3, int wexp = 0, float* amax_io = nullptr,
-                          float amax_first = 0.0f);
+                          float amax_first = 0.0f, const float* head_w = nullptr, const float* head_b = nullptr);
 int launch_conv3x3_wino(int S, const float* in, const float* wt_wino, const float* bias, const float* resid, float* out,
                         int nboards, hipStream_t st);
 // act_is_h: `act` is not the trunk's output [board][P][128] but the heads' 1x1 convolutions of it, [board][3][P]

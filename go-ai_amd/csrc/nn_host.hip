@@ -157,7 +157,8 @@ static int nn_init_impl(goai_ctx* c, int kind, int layers, int max_batch, int dt
         if ((rc = dev_alloc(c, (void**)&n.act[i], (size_t)max_batch * P * 128 * sizeof(float)))) return rc;
     // The split F(3x3,3x3) trunk in one launch ends with the heads' three 1x1 convolutions (conv_wino3s_kernels.hip): its
     // last convolution's 128 channels never go to memory.  GOAI_NO_HEAD_FUSION=1: the heads do them, as everywhere else.
-    n.heads_in_trunk = layers > 0 && n.split6 && n.wino_mode == 3 && n.trunk_fused && !getenv("GOAI_NO_HEAD_FUSION");
+    n.heads_in_trunk = layers > 0 && n.split6 && (n.wino_mode == 2 || (n.wino_mode == 3 && n.trunk_fused)) &&
+                       !getenv("GOAI_NO_HEAD_FUSION");
     if (n.heads_in_trunk && (rc = dev_alloc(c, (void**)&n.hbuf, (size_t)max_batch * 3 * P * sizeof(float)))) return rc;
     return GOAI_OK;
 }
@@ -446,7 +447,9 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
     return GOAI_OK;
 }
 
-static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const float* resid, float* out, int M)
+// heads: the trunk's last convolution of a Net::heads_in_trunk context (split F(2x2,3x3)): `out` = net.hbuf receives the
+// heads' 1x1 convolutions of the output instead of the output
+static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const float* resid, float* out, int M, bool heads = false)
 {
     const Net& net = c->net;
     if (net.dtype == GOAI_DTYPE_BF16X3)
@@ -456,7 +459,8 @@ static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const f
     // fp16 parts: the first convolution's input is bounded by amax0, every launch leaves its output's bounds in net.amax
     if (net.split6 && net.wino_mode == 2)
         return launch_conv3x3_wino2s(c->S, in, (const uint16_t*)net.wt_split6 + (size_t)l * wt_split_per_conv(net), b, resid, out,
-                                     M / c->P, c->stream, net.parts, net.wexp_host[l], net.amax, l == 0 ? net.amax0 : 0.0f);
+                                     M / c->P, c->stream, net.parts, net.wexp_host[l], net.amax, l == 0 ? net.amax0 : 0.0f,
+                                     heads ? net.hw.conv_w : nullptr, net.hw.conv_b);
     if (net.split6)
         return launch_conv3x3_wino3s(c->S, const_cast<float*>(in), out, resid,
                                      (const uint16_t*)net.wt_split6 + (size_t)l * wt_split_per_conv(net), b, net.wino3p_tab, M / c->P, 1,
@@ -472,16 +476,16 @@ static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const f
     return launch_conv3x3(c->S, in, net.wt + (size_t)l * 9 * 128 * 128, b, resid, out, M, c->stream);
 }
 
-static int timed_conv(goai_ctx* c, const float* in, int l, const float* b, const float* resid, float* out, int M)
+static int timed_conv(goai_ctx* c, const float* in, int l, const float* b, const float* resid, float* out, int M, bool heads = false)
 {
-    if (!c->prof_enabled) return conv_any(c, in, l, b, resid, out, M);
+    if (!c->prof_enabled) return conv_any(c, in, l, b, resid, out, M, heads);
     hipEvent_t e0, e1;
     GOAI_HIP_CHECK(hipEventCreate(&e0));
     GOAI_HIP_CHECK(hipEventCreate(&e1));
     c->prof_events.push_back(e0);
     c->prof_events.push_back(e1);
     GOAI_HIP_CHECK(hipEventRecord(e0, c->stream));
-    int rc = conv_any(c, in, l, b, resid, out, M);
+    int rc = conv_any(c, in, l, b, resid, out, M, heads);
     GOAI_HIP_CHECK(hipEventRecord(e1, c->stream));
     return rc;
 }
@@ -527,16 +531,21 @@ static int nn_trunk_on(goai_ctx* c, float* const act[3], int nb, bool prof, floa
         }
     } else
     for (int l = 0; l < net.layers; l++) {
+        const bool heads = net.heads_in_trunk && net.wino_mode == 2 && l == net.layers - 1;
         if (prof) {
             if ((rc = timed_conv(c, x, 2 * l, net.bt + (size_t)(2 * l) * 128, nullptr, y, M))) return rc;
-            if ((rc = timed_conv(c, y, 2 * l + 1, net.bt + (size_t)(2 * l + 1) * 128, x, z, M))) return rc;
+            if ((rc = timed_conv(c, y, 2 * l + 1, net.bt + (size_t)(2 * l + 1) * 128, x, heads ? net.hbuf : z, M, heads))) return rc;
         } else {
             if ((rc = conv_any(c, x, 2 * l, net.bt + (size_t)(2 * l) * 128, nullptr, y, M))) return rc;
-            if ((rc = conv_any(c, y, 2 * l + 1, net.bt + (size_t)(2 * l + 1) * 128, x, z, M))) return rc;
+            if ((rc = conv_any(c, y, 2 * l + 1, net.bt + (size_t)(2 * l + 1) * 128, x, heads ? net.hbuf : z, M, heads))) return rc;
         }
         float* t = x; x = z; z = t;
     }
     *out = x;
+    if (net.heads_in_trunk && net.wino_mode == 2 && net.layers > 0) {
+        *out = net.hbuf;
+        *out_is_h = true;
+    }
     return GOAI_OK;
 }
 

@@ -361,21 +361,22 @@ def test_split_forward_is_fp32_grade(size, kind, n, layers, max_batch, split, mo
     assert err["split"] < 2.0 * err["fp32"] + 2e-6      # at the fp32 kernel's own level
 
 
+@pytest.mark.parametrize("size,n,layers", [(9, 203, 3), (13, 45, 3), (19, 7, 2), (5, 77, 3), (7, 50, 3)])
 @pytest.mark.parametrize("kind,dtype", [("ac", "f16x3"), ("val", "f16x3"), ("ac", "bf16x6")])
-def test_heads_formed_by_the_trunk_launch(kind, dtype, monkeypatch):
-    """9x9 split-dtype contexts: the trunk launch ends with the heads' 1x1 convolutions (its last convolution never goes
-    to memory; conv_wino3s_kernels.hip, head_out).  Same network outputs as with GOAI_NO_HEAD_FUSION=1 (k_heads does the
+def test_heads_formed_by_the_trunk_launch(kind, dtype, size, n, layers, monkeypatch):
+    """Split-dtype contexts: the trunk's last launch ends with the heads' 1x1 convolutions (its last convolution never goes
+    to memory; conv_wino3s_kernels.hip head_out, conv_wino2s_kernels.hip HEADS).  Same network outputs as with GOAI_NO_HEAD_FUSION=1 (k_heads does the
     1x1 convolutions from the stored activations) up to the order of the 128 additions, and both within the fp32
     tolerance of the torch oracle; odd batch sizes, the last workgroup partly empty."""
     from go_ai.engine import Context
-    states = random_positions(9, 203, seed=5, canonical=True, pass_prob=0.05)
+    states = random_positions(size, n, seed=5, canonical=True, pass_prob=0.05)
     outs = []
     for env in (None, "1"):
         if env:
             monkeypatch.setenv("GOAI_NO_HEAD_FUSION", env)
         else:
             monkeypatch.delenv("GOAI_NO_HEAD_FUSION", raising=False)
-        c, sd = make_ctx(kind, 9, 31, 3, 256, dtype=Context.DTYPE_F16X3 if dtype == "f16x3" else Context.DTYPE_BF16X6)
+        c, sd = make_ctx(kind, size, 31, layers, 256, dtype=Context.DTYPE_F16X3 if dtype == "f16x3" else Context.DTYPE_BF16X6)
         pi, val = c.nn_forward(states, mode=c.NN_RAW)
         outs.append((pi.cpu().numpy() if kind == "ac" else None, val.cpu().numpy()))
         c.close()
