@@ -389,3 +389,36 @@ def test_heads_formed_by_the_trunk_launch(kind, dtype, size, n, layers, monkeypa
     assert rel_err(outs[0][1], outs[1][1]) < 1e-5
     if kind == "ac":
         assert rel_err(outs[0][0], outs[1][0]) < 1e-5
+
+
+@pytest.mark.parametrize("size,layers", [(9, 3), (13, 2), (9, 10)])
+@pytest.mark.parametrize("gain", [3e4, 1.0 / 4096, 1.0])
+def test_f16x3_scales_follow_the_activations(size, layers, gain):
+    """GOAI_DTYPE_F16X3 on networks whose activations are far from fp16's range: the first BatchNorm's affine
+    part scaled by `gain` puts the trunk's activations at ~1e5 (fp16 overflows at 65,504, and the
+    Winograd-transformed values are up to 36 times larger) or ~1e-4 (second parts of most values below fp16's smallest
+    normal number).  Per-board power-of-two scales must keep the error, relative to the outputs' own size, where it is
+    for ordinary weights; boards of very different size share workgroups (every other board is empty = smallest
+    activations)."""
+    from go_ai.engine import Context
+    sd = nn_ref.make_state_dict("ac", size, 77, layers)
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["main.1.weight"] *= gain                # the first BatchNorm's output, i.e. the trunk's input, scaled by `gain`
+    sd["main.1.bias"] *= gain
+    states = random_positions(size, 37, seed=3, canonical=True, pass_prob=0.05)
+    states[::2] = 0
+    outs = {}
+    for name, dtype in (("f16x3", Context.DTYPE_F16X3), ("f32", Context.DTYPE_F32)):
+        c = Context(size)
+        c.nn_init(Context.NET_AC, layers, 64, dtype=dtype)
+        c.load_weights(sd)
+        pi, val = c.nn_forward(states, mode=c.NN_RAW)
+        outs[name] = (pi.cpu().numpy().astype(np.float64), val.cpu().numpy().astype(np.float64))
+        c.close()
+    want_pi, want_val = nn_ref.forward(sd, torch.tensor(states), "ac")
+    want_pi, want_val = want_pi.numpy().astype(np.float64), want_val.numpy().astype(np.float64)
+    assert np.isfinite(outs["f16x3"][0]).all() and np.isfinite(outs["f16x3"][1]).all()
+    scale_pi, scale_val = max(1.0, float(np.abs(want_pi).max())), max(1.0, float(np.abs(want_val).max()))
+    err = {k: max(np.abs(v[0] - want_pi).max() / scale_pi, np.abs(v[1] - want_val).max() / scale_val) for k, v in outs.items()}
+    print(f"gain {gain:g} {size}x{size} L{layers}: f16x3 {err['f16x3']:.2e}, f32 kernels {err['f32']:.2e} (logits up to {scale_pi:.3g})")
+    assert err["f16x3"] < 3.0 * err["f32"] + 1e-5
