@@ -380,10 +380,14 @@ def main():
     if rank == 0:
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "conv3x3_traffic.json")
-        if os.path.exists(tpath) and args.config == "c2":          # recorded PMC passes of THIS workload, per kernel
+        if os.path.exists(tpath):          # recorded PMC passes of THIS workload (default dtype, default games), per kernel
             rec = json.load(open(tpath))
-            traffic = rec.get("per_kernel", {}).get(kname.split("<")[0], {}).get("hbm_bytes_per_launch")
-            traffic_src = f"recorded rocprofv3 --pmc passes, profiles/conv3x3_traffic.json ({rec.get('recorded', 'round 1')})"
+            if args.config == "c2":
+                traffic = rec.get("per_kernel", {}).get(kname.split("<")[0], {}).get("hbm_bytes_per_launch")
+            elif rec.get("per_config", {}).get(args.config, {}).get("kernel") == kname.split("<")[0] and args.dtype == "f16x3":
+                traffic = rec["per_config"][args.config]["hbm_bytes_per_launch"]
+            if traffic is not None:
+                traffic_src = f"recorded rocprofv3 --pmc passes, profiles/conv3x3_traffic.json ({rec.get('recorded', 'round 1')})"
         out = {
             "metric": f"MCTS leaf evals/sec ({SIZE}x{SIZE}, transition + NN forward)",
             "value": round(total_evals / t_max, 1),
