@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(ROOT, "go-ai_amd")); sys.path.insert(0, ROOT)
 from go_ai import _hip
 from go_ai.game import BatchedSelfPlay
 from go_ai.engine import Context
-sp = BatchedSelfPlay(9, 1024, 81, seed=1234, dtype=Context.DTYPE_BF16X6, refill=True)
+sp = BatchedSelfPlay(9, 1024, 81, seed=1234, dtype=Context.DTYPE_F16X3, refill=True)
 sp.play(3)
 sp.sync()
 n = 512
