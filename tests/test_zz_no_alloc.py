@@ -16,24 +16,27 @@ from oracle import nn_ref
 pytestmark = pytest.mark.gpu
 
 
-def _ctx(kind, size, layers, max_batch, seed=3):
+def _ctx(kind, size, layers, max_batch, seed=3, dtype=0):
     from go_ai.engine import Context
     c = Context(size)
-    c.nn_init(Context.NET_AC if kind == "ac" else Context.NET_VAL, layers, max_batch)
+    c.nn_init(Context.NET_AC if kind == "ac" else Context.NET_VAL, layers, max_batch, dtype=dtype)
     c.load_weights(nn_ref.make_state_dict(kind, size, seed, layers))
     return c
 
 
-@pytest.mark.parametrize("kind,size,layers,max_batch,n1,n2", [
-    ("ac", 9, 3, 1024, 101, 37),     # F(3x3,3x3) paired trunk in one launch; 101 boards = the limit at 9x9
-    ("ac", 9, 3, 4096, 90, 5),       # F(3x3,3x3), one chunk
-    ("val", 9, 3, 64, 64, 1),        # direct implicit GEMM, value head
-    ("ac", 13, 3, 512, 48, 17),      # F(2x2,3x3); 48 boards = the limit at 13x13
-    ("ac", 19, 10, 512, 22, 3),      # the deeper trunk; 22 boards = the limit at 19x19
-    ("ac", 5, 3, 16, 40, 7),         # slices of max_batch = 16 inside one call
+@pytest.mark.parametrize("kind,size,layers,max_batch,n1,n2,dtype", [
+    ("ac", 9, 3, 1024, 101, 37, 0),     # F(3x3,3x3) paired trunk in one launch; 101 boards = the limit at 9x9
+    ("ac", 9, 3, 4096, 90, 5, 0),       # F(3x3,3x3), one chunk
+    ("val", 9, 3, 64, 64, 1, 0),        # direct implicit GEMM, value head
+    ("ac", 13, 3, 512, 48, 17, 0),      # F(2x2,3x3); 48 boards = the limit at 13x13
+    ("ac", 19, 10, 512, 22, 3, 0),      # the deeper trunk; 22 boards = the limit at 19x19
+    ("ac", 5, 3, 16, 40, 7, 0),         # slices of max_batch = 16 inside one call
+    ("ac", 9, 3, 1024, 101, 37, 3),  # GOAI_DTYPE_F16X3 (what bench.py runs): F(3x3,3x3), heads' 1x1 in the trunk launch
+    ("ac", 13, 3, 64, 48, 17, 3),    # ... F(2x2,3x3): the boards' bounds travel between launches
+    ("val", 9, 3, 16, 40, 3, 3),     # ... slices, value head
 ])
-def test_static_forward_equals_forward_twice(kind, size, layers, max_batch, n1, n2):
-    c = _ctx(kind, size, layers, max_batch)
+def test_static_forward_equals_forward_twice(kind, size, layers, max_batch, n1, n2, dtype):
+    c = _ctx(kind, size, layers, max_batch, dtype=dtype)
     A = size * size + 1
     states = torch.from_numpy(random_positions(size, n1, seed=size + n1, canonical=True, pass_prob=0.05)).to(c.device)
     for mode in (c.NN_RAW, c.NN_NUMPY_SHIM):
