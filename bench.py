@@ -349,6 +349,18 @@ def main():
         wgs = -(-nb // 4) if -(-nb // 4) <= n_cu else -(-nb // 5)
         # (the two-chunk kernel runs 32 rows as 16x16x4 tiles and the other 4 as 4x4x1 blocks: no padded rows)
         executed_flop = 2.0 * wgs * (36 if algo == 4 else 48) * 25 * 128 * 128 * cpl
+    lds_info = {}
+    if algo == 7:
+        # What this kernel really waits for besides instruction issue: LDS.  Per convolution and workgroup (DESIGN.md section 5,
+        # profiles/r02_wino3s_ablation.txt): V fragment reads 50 stages x 8 waves x 6 tile steps x 2 parts x 1 KB = 4.8 MB, the
+        # input transform's patch + table reads 1152 items x 1536 B = 1.77 MB, its V writes 1152 x 25 x 2 x 8 B = 0.46 MB,
+        # image hand-over 0.17 MB; peak 128 B per clock and CU at 2.4 GHz.
+        n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        lds_bytes = wgs * cpl * (4.8e6 + 1.77e6 + 0.46e6 + 0.17e6)
+        lds_peak = n_cu * 128 * 2.4e9
+        lds_info = {"lds": {"bytes_per_launch": lds_bytes, "achieved_TBps": round(lds_bytes / launch_s / 1e12, 2),
+                            "peak_TBps": round(lds_peak / 1e12, 1), "frac": round(lds_bytes / launch_s / lds_peak, 4),
+                            "note": "analytic LDS bytes of the launch; the matrix pipe is not what this kernel waits for"}}
     achieved = executed_flop / launch_s / 1e12           # TFLOP/s the matrix pipe sustains
     effective = conv_flop / launch_s / 1e12              # the convolution's own flops per second (Winograd executes fewer)
 
@@ -411,7 +423,7 @@ def main():
                        "stream_groups_per_gpu": len(sp.groups),
                        "finished_games": "slot starts the next game from the empty board" if not args.no_refill else "slot idles",
                        "weights": "random init, seed 0", "leaf_evals_timed": int(total_evals)},
-            "roofline": {"bound": "mfma", "kernel": kname,
+            "roofline": {"bound": "mfma", "kernel": kname, **lds_info,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_us": round(launch_s * 1e6, 2), "launches_timed": conv_n,
