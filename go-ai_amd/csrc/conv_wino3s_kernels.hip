@@ -100,6 +100,11 @@ __device__ __forceinline__ f32x4 s_fma4(float c, f32x4 a, f32x4 b)
 {
     return f32x4{ fmaf(c, a[0], b[0]), fmaf(c, a[1], b[1]), fmaf(c, a[2], b[2]), fmaf(c, a[3], b[3]) };
 }
+// A V row is 64 B = four 16-byte quarters (8 channels each).  An MFMA fragment read (ds_read_b128, lane (li, lq) = row li,
+// quarter lq) is served in groups of 16 lanes = rows {0-3, 12-15} at one quarter + rows {4-11} at the next: with the
+// quarters in place these touch 32 of the 64 banks twice.  Quarter q of row r therefore sits at position q ^ w3s_vswz(r),
+// which spreads every such group over all 64 banks (SQ_LDS_BANK_CONFLICT: 44 % of the LDS cycles before).
+__device__ __forceinline__ int w3s_vswz(int row) { return (0 - (row >> 2)) & 3; }
 // two fp32 bit patterns whose low halves are dropped -> one word of two bf16 (a in the low half)
 __device__ __forceinline__ unsigned s_pack(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
@@ -173,7 +178,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
         // wtile 8 of board b -> row 32 + b (the third tile; its columns 4..15 read the zero row).
         const int tvrow = (ttw % W::T2 < 8) ? (ttw / W::T2) * 8 + ttw % W::T2 : 32 + ttw / W::T2;
         return TItem{ (unsigned)(tc * (W::IMG_CH_U4 * 16) + ts * 16), (unsigned)((2 * W::IMG_CH_U4 + W::V_U4 + ttw * 5) * 16),
-                      (unsigned)((2 * W::IMG_CH_U4 + tc * (5 * NP * W::V_PART_U4)) * 16 + (tvrow * 8 + ts) * 8), ttw / W::T2 };
+                      (unsigned)((2 * W::IMG_CH_U4 + tc * (5 * NP * W::V_PART_U4)) * 16 + tvrow * 64 +
+                                 (((ts >> 1) ^ w3s_vswz(tvrow)) * 16) + (ts & 1) * 8), ttw / W::T2 };
     };
     const TItem it0 = t_item(4 * wave + t_g), it1 = t_item(32 + t_g);
 
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
     unsigned vaddr[MT];                              // LDS byte address of the lane's fragment of (chunk 0, q 0, part 0) per column tile
 #pragma unroll
     for (int t = 0; t < MT; t++) {
-        vaddr[t] = (unsigned)((2 * W::IMG_CH_U4 + lq + vrow[t] * 4) * 16);
+        vaddr[t] = (unsigned)((2 * W::IMG_CH_U4 + (lq ^ w3s_vswz(vrow[t])) + vrow[t] * 4) * 16);
         asm volatile("" : "+v"(vaddr[t]));           // (a register, not a constant to be folded into each read's address again)
     }
 
