@@ -422,3 +422,28 @@ def test_f16x3_scales_follow_the_activations(size, layers, gain):
     err = {k: max(np.abs(v[0] - want_pi).max() / scale_pi, np.abs(v[1] - want_val).max() / scale_val) for k, v in outs.items()}
     print(f"gain {gain:g} {size}x{size} L{layers}: f16x3 {err['f16x3']:.2e}, f32 kernels {err['f32']:.2e} (logits up to {scale_pi:.3g})")
     assert err["f16x3"] < 3.0 * err["f32"] + 1e-5
+
+
+@pytest.mark.parametrize("dtype", ["f16x3", "bf16x6"])
+def test_split_trunk_in_one_launch_equals_one_launch_per_convolution(dtype, monkeypatch):
+    """9x9 split-dtype contexts with GOAI_NO_TRUNK_FUSION=1 launch k_conv3x3_wino3s once per convolution: the boards'
+    activation bounds then travel through Net::amax between launches (instead of LDS), every convolution stages its whole
+    image from memory (no LDS hand-over), and k_heads forms the 1x1 convolutions.  The convolutions' arithmetic is the
+    same, so the value / policy outputs agree to the order of the heads' 128 additions."""
+    from go_ai.engine import Context
+    states = random_positions(9, 77, seed=5, canonical=True, pass_prob=0.05)
+    outs = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("GOAI_NO_TRUNK_FUSION", env)
+        else:
+            monkeypatch.delenv("GOAI_NO_TRUNK_FUSION", raising=False)
+        c, sd = make_ctx("ac", 9, 31, 3, 64, dtype=Context.DTYPE_F16X3 if dtype == "f16x3" else Context.DTYPE_BF16X6)
+        assert c.nn_convs_per_launch() == (1 if env else 6)
+        pi, val = c.nn_forward(states, mode=c.NN_RAW)
+        outs.append((pi.cpu().numpy(), val.cpu().numpy()))
+        c.close()
+    monkeypatch.delenv("GOAI_NO_TRUNK_FUSION", raising=False)
+    assert rel_err(outs[0][1], outs[1][1]) < 1e-5 and rel_err(outs[0][0], outs[1][0]) < 1e-5
+    want_pi, want_val = nn_ref.forward(sd, torch.tensor(states), "ac")
+    assert rel_err(outs[1][1], want_val.numpy()) < 1e-5 and rel_err(outs[1][0], want_pi.numpy()) < 2e-5
