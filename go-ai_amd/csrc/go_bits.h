@@ -221,6 +221,9 @@ __device__ __forceinline__ int bits_next_state(const BB<S>& me, const BB<S>& opp
 // choose).  P = 1 (mod 4) for every board size, so a plane is (P - 1) / 4 whole words and one last byte.
 __device__ __forceinline__ uint32_t lds_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ void lds_put_u32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+// eight bytes at any alignment (one unaligned ds_read_b64 / ds_write_b64)
+__device__ __forceinline__ uint64_t lds_u64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ void lds_put_u64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
 // bit 7 of every byte of x that is not zero
 __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) { return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; }
 // the four flags (bit 7 of each byte) as bits 0..3
@@ -238,8 +241,8 @@ __device__ __forceinline__ uint32_t spread4(uint32_t n) { return __umul24(n & 0x
 template <int S>
 __device__ __forceinline__ int record_load(const uint8_t* rec, int action, BB<S>& me, BB<S>& opp, bool& inv_at, uint32_t& flags)
 {
-    constexpr int P = BitGeom<S>::P, NW = BitGeom<S>::NW, ND = P / 4;      // whole words per plane; byte P - 1 is left over
-    static_assert(P % 4 == 1, "odd board sizes");
+    constexpr int P = BitGeom<S>::P, NW = BitGeom<S>::NW, ND = P / 8;      // whole 8-byte pieces per plane; byte P - 1 is left over
+    static_assert(P % 8 == 1, "odd board sizes");
     uint32_t c0[2 * NW], c1[2 * NW];
 #pragma unroll
     for (int h = 0; h < 2 * NW; h++) { c0[h] = 0; c1[h] = 0; }
@@ -247,14 +250,16 @@ __device__ __forceinline__ int record_load(const uint8_t* rec, int action, BB<S>
 #pragma unroll
     for (int h = 0; h < 2 * NW; h++) {
 #pragma unroll
-        for (int n = 0; n < 8; n++) {                            // cells 32 h + 4 n .. + 3 -> bits 4 n .. of word h
-            const int j = 8 * h + n;
+        for (int n = 0; n < 4; n++) {                            // cells 32 h + 8 n .. + 7 -> bits 8 n .. of word h
+            const int j = 4 * h + n;
             if (j < ND) {
-                c0[h] |= gather4(nonzero_bytes(lds_u32(rec + 4 * j))) << (4 * n);
-                c1[h] |= gather4(nonzero_bytes(lds_u32(rec + P + 4 * j))) << (4 * n);
-                any_turn |= lds_u32(rec + 2 * P + 4 * j);
-                any_pass |= lds_u32(rec + 4 * P + 4 * j);
-                all_done &= nonzero_bytes(lds_u32(rec + 5 * P + 4 * j));
+                const uint64_t a = lds_u64(rec + 8 * j), b = lds_u64(rec + P + 8 * j), t = lds_u64(rec + 2 * P + 8 * j),
+                               ps = lds_u64(rec + 4 * P + 8 * j), dn = lds_u64(rec + 5 * P + 8 * j);
+                c0[h] |= (gather4(nonzero_bytes((uint32_t)a)) | gather4(nonzero_bytes((uint32_t)(a >> 32))) << 4) << (8 * n);
+                c1[h] |= (gather4(nonzero_bytes((uint32_t)b)) | gather4(nonzero_bytes((uint32_t)(b >> 32))) << 4) << (8 * n);
+                any_turn |= (uint32_t)t | (uint32_t)(t >> 32);
+                any_pass |= (uint32_t)ps | (uint32_t)(ps >> 32);
+                all_done &= nonzero_bytes((uint32_t)dn) & nonzero_bytes((uint32_t)(dn >> 32));
             }
         }
     }
@@ -283,9 +288,11 @@ template <int S>
 __device__ __forceinline__ void record_store(uint8_t* rec, bool legal, const BB<S>& ch0, const BB<S>& ch1, const BB<S>& inv, int turn,
                                              uint32_t flags)
 {
-    constexpr int P = BitGeom<S>::P, NW = BitGeom<S>::NW, ND = P / 4;
+    constexpr int P = BitGeom<S>::P, NW = BitGeom<S>::NW, ND = P / 8;
     const uint32_t t = (legal && turn) ? 0x01010101u : 0u, ps = (legal && (flags & FLAG_PASS)) ? 0x01010101u : 0u,
                    dn = (legal && (flags & FLAG_DONE)) ? 0x01010101u : 0u;
+    const uint64_t t8 = ((uint64_t)t << 32) | t, ps8 = ((uint64_t)ps << 32) | ps, dn8 = ((uint64_t)dn << 32) | dn;
+    auto spread8 = [](uint32_t n) { return ((uint64_t)spread4(n >> 4) << 32) | spread4(n); };
     uint32_t a[2 * NW], b[2 * NW], v[2 * NW];
 #pragma unroll
     for (int h = 0; h < 2 * NW; h++) {
@@ -296,15 +303,15 @@ __device__ __forceinline__ void record_store(uint8_t* rec, bool legal, const BB<
 #pragma unroll
     for (int h = 0; h < 2 * NW; h++) {
 #pragma unroll
-        for (int n = 0; n < 8; n++) {
-            const int j = 8 * h + n;
+        for (int n = 0; n < 4; n++) {
+            const int j = 4 * h + n;
             if (j < ND) {
-                lds_put_u32(rec + 4 * j, spread4(a[h] >> (4 * n)));
-                lds_put_u32(rec + P + 4 * j, spread4(b[h] >> (4 * n)));
-                lds_put_u32(rec + 2 * P + 4 * j, t);
-                lds_put_u32(rec + 3 * P + 4 * j, spread4(v[h] >> (4 * n)));
-                lds_put_u32(rec + 4 * P + 4 * j, ps);
-                lds_put_u32(rec + 5 * P + 4 * j, dn);
+                lds_put_u64(rec + 8 * j, spread8(a[h] >> (8 * n)));
+                lds_put_u64(rec + P + 8 * j, spread8(b[h] >> (8 * n)));
+                lds_put_u64(rec + 2 * P + 8 * j, t8);
+                lds_put_u64(rec + 3 * P + 8 * j, spread8(v[h] >> (8 * n)));
+                lds_put_u64(rec + 4 * P + 8 * j, ps8);
+                lds_put_u64(rec + 5 * P + 8 * j, dn8);
             }
         }
     }
