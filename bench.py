@@ -360,7 +360,9 @@ def main():
         lds_peak = n_cu * 128 * 2.4e9
         lds_info = {"lds": {"bytes_per_launch": lds_bytes, "achieved_TBps": round(lds_bytes / launch_s / 1e12, 2),
                             "peak_TBps": round(lds_peak / 1e12, 1), "frac": round(lds_bytes / launch_s / lds_peak, 4),
-                            "note": "analytic LDS bytes of the launch; the matrix pipe is not what this kernel waits for"}}
+                            "note": "analytic LDS bytes of the launch at 128 B per clock and CU; SQ_LDS_IDX_ACTIVE measures 0.31 of the "
+                                    "launch's CU cycles (profiles/r02_wino3s_ablation.txt).  Neither the matrix pipe nor LDS is what "
+                                    "this kernel waits for: its SIMDs issue ~146 instructions per stage and wave at ~4.6 cycles each"}}
     achieved = executed_flop / launch_s / 1e12           # TFLOP/s the matrix pipe sustains
     effective = conv_flop / launch_s / 1e12              # the convolution's own flops per second (Winograd executes fewer)
 
