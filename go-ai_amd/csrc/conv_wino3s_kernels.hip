@@ -252,11 +252,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
         auto put = [&](int q, const f32x4 v) {
             if constexpr (NP == 2) {
                 // two fp16 parts, round to nearest: h = fp16(v), l = fp16(v - h) (the difference is exact in fp32)
+                // (vs - h by v_fma_mix_f32, which reads h's halves in place: one instruction per value instead of a
+                // conversion back and a subtraction -- the vector ALU's issue is what this kernel is bound by)
                 const f32x4 vs = v * t_scale;
                 const f16x4 h = __builtin_convertvector(vs, f16x4);
-                const f16x4 l = __builtin_convertvector(vs - __builtin_convertvector(h, f32x4), f16x4);
+                const uint2 hp = __builtin_bit_cast(uint2, h);
+                f32x4 rest;
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(rest[0]) : "v"(hp.x), "v"(vs[0]));
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rest[1]) : "v"(hp.x), "v"(vs[1]));
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(rest[2]) : "v"(hp.y), "v"(vs[2]));
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rest[3]) : "v"(hp.y), "v"(vs[3]));
+                const f16x4 l = __builtin_convertvector(rest, f16x4);
                 uint2* dst = V + q * (2 * W::V_PART_U4 * 2);
-                dst[0] = __builtin_bit_cast(uint2, h);
+                dst[0] = hp;
                 dst[W::V_PART_U4 * 2] = __builtin_bit_cast(uint2, l);
             } else {
             unsigned h[4], m[4], l[4];
