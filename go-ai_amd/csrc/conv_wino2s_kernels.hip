@@ -156,11 +156,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
             auto put = [&](int q, const f32x4 v) {
                 if constexpr (NP == 2) {
                     // two fp16 parts, round to nearest: h = fp16(v), l = fp16(v - h) (the difference is exact in fp32)
-                    const f16x4 h = __builtin_convertvector(v, f16x4);
-                    const f16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), f16x4);
+                    // (l by v_fma_mixlo / mixhi_f16: reads h's halves in place, subtracts in fp32, writes a half register)
+                    const uint2 hp = __builtin_bit_cast(uint2, __builtin_convertvector(v, f16x4));
+                    uint2 lp;
+                    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lp.x) : "v"(hp.x), "v"(v[0]));
+                    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp.x) : "v"(hp.x), "v"(v[1]));
+                    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lp.y) : "v"(hp.y), "v"(v[2]));
+                    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp.y) : "v"(hp.y), "v"(v[3]));
                     uint2* dst = V + q * (2 * W::V_PART_U4 * 2);
-                    dst[0] = __builtin_bit_cast(uint2, h);
-                    dst[W::V_PART_U4 * 2] = __builtin_bit_cast(uint2, l);
+                    dst[0] = hp;
+                    dst[W::V_PART_U4 * 2] = lp;
                 } else {
                 unsigned h[4], m[4], l[4];
 #pragma unroll
