@@ -386,8 +386,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
             for (int t = 0; t < MT; t++) vq[t] = vaddr[t];
 #pragma unroll
             for (int a = 0; a < AH; a++) v_read_step(a, vf[a]);
-#pragma unroll 1
-            for (int q = 0; q < 5; q++) {
+            // one stage (q = the column of the row's five); JM = which output columns j its factors At[j][q] reach
+            // (q = 0: only j = 0, q = 4: only j = 2 -- those two stages are peeled so that their zero factors cost nothing:
+            // the vector ALU's issue is what a stage waits for)
+            auto stage = [&](const int q, auto jmask) {
+                constexpr int JM = decltype(jmask)::value;
                 f32x4 m[MT];
 #pragma unroll
                 for (int t = 0; t < MT; t++) m[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
@@ -454,16 +457,20 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
                         for (int t = 0; t < MT; t++)
 #pragma unroll
                             for (int e = 0; e < 4; e++) {
-                                Y[i][0][t][e] = fmaf(f0, m[t][e], Y[i][0][t][e]);
-                                Y[i][1][t][e] = fmaf(f1, m[t][e], Y[i][1][t][e]);
-                                Y[i][2][t][e] = fmaf(f2, m[t][e], Y[i][2][t][e]);
+                                if (JM & 1) Y[i][0][t][e] = fmaf(f0, m[t][e], Y[i][0][t][e]);
+                                if (JM & 2) Y[i][1][t][e] = fmaf(f1, m[t][e], Y[i][1][t][e]);
+                                if (JM & 4) Y[i][2][t][e] = fmaf(f2, m[t][e], Y[i][2][t][e]);
                             }
                     }
                 }
 #pragma unroll
                 for (int t = 0; t < MT; t++) vq[t] += NP * W::V_PART_U4 * 16;
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            };
+            stage(0, std::integral_constant<int, 1>{});
+#pragma unroll 1
+            for (int q = 1; q < 4; q++) stage(q, std::integral_constant<int, 7>{});
+            stage(4, std::integral_constant<int, 4>{});
             __syncthreads();                                   // every wave has read this row of V
             W3S_STAMP(3 + 2 * (5 * cp + p));
             if (stage_next) {
