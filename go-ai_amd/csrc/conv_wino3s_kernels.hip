@@ -391,9 +391,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
             // the vector ALU's issue is what a stage waits for)
             auto stage = [&](const int q, auto jmask) {
                 constexpr int JM = decltype(jmask)::value;
+                // the four corner stages (p, q in {0, 4}) reach one output each, with factor 1: their MFMAs accumulate
+                // straight into it
+                const bool corner = (JM == 1 || JM == 4) && (p == 0 || p == 4);
+                const int ci_c = (p == 0) ? 0 : 2, cj_c = (JM == 1) ? 0 : 2;
                 f32x4 m[MT];
 #pragma unroll
-                for (int t = 0; t < MT; t++) m[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+                for (int t = 0; t < MT; t++) m[t] = corner ? Y[ci_c][cj_c][t] : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
                     const int h = c;                                       // half-stage of this stage; its weights sit in wf[c]
@@ -451,7 +455,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
                     const int ci = (i == 0) ? (p < 4 ? 1 : 0)
                                  : (i == 1) ? (p == 1 ? 1 : (p == 2 ? -1 : (p == 3 ? 2 : 0)))
                                             : (p == 0 ? 0 : (p == 3 ? 4 : 1));
-                    if (ci != 0 && !(W3S_DIAG & 2)) {
+                    if (corner) {
+                        if (i == ci_c) {
+#pragma unroll
+                            for (int t = 0; t < MT; t++) Y[ci_c][cj_c][t] = m[t];
+                        }
+                    } else if (ci != 0 && !(W3S_DIAG & 2)) {
                         const float f0 = (float)ci * cj0, f1 = (float)ci * cj1, f2 = (float)ci * cj2;
 #pragma unroll
                         for (int t = 0; t < MT; t++)
