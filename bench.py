@@ -362,7 +362,7 @@ def main():
                             "peak_TBps": round(lds_peak / 1e12, 1), "frac": round(lds_bytes / launch_s / lds_peak, 4),
                             "note": "analytic LDS bytes of the launch at 128 B per clock and CU; SQ_LDS_IDX_ACTIVE measures 0.31 of the "
                                     "launch's CU cycles (profiles/r02_wino3s_ablation.txt).  Neither the matrix pipe nor LDS is what "
-                                    "this kernel waits for: its SIMDs issue ~146 instructions per stage and wave at ~4.6 cycles each"}}
+                                    "this kernel waits for: its SIMDs are bound by instruction issue (a stage = 36 MFMAs at 17 cycles + ~56 packed fmas at 4.9 + reads and loads, and MFMAs and vector instructions do not overlap: tools/ubench/mfma_f16_valu.hip)"}}
     achieved = executed_flop / launch_s / 1e12           # TFLOP/s the matrix pipe sustains
     effective = conv_flop / launch_s / 1e12              # the convolution's own flops per second (Winograd executes fewer)
 
