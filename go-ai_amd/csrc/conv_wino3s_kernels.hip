@@ -354,8 +354,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
             const bool stage_next = (p == 4 && cp == 0);       // chunks 2, 3 replace 0, 1 behind the last transform
             if (stage_next) load_img(2);
             if (!(W3S_DIAG & 8) || (p == 0 && cp == 0)) {
-                transform(p, it0);
-                if (wave == 0) transform(p, it1);
+                // one body for both passes (wave 0's second pass then runs code that is already in the instruction cache)
+#pragma unroll 1
+                for (int pass = 0; pass < (wave == 0 ? 2 : 1); pass++) {
+                    TItem it = it0;
+                    if (pass) it = it1;
+                    transform(p, it);
+                }
             }
             __syncthreads();                                   // V complete; (p == 4) the image is dead
             W3S_STAMP(2 + 2 * (5 * cp + p));
