@@ -372,7 +372,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3s(float* x, float* y, cons
             // pipelined: the V fragments of step n + AH are read from LDS while the MFMAs of step n run, and the weights of
             // half-stage h + 1 = (q, c) + 1 are requested at the top of half-stage h (two register sets,
             // alternating: no copies, so nothing waits for a load before its data is needed).
-            constexpr int AH = 1, RING = AH + 1;               // (AH = 2 with three MFMAs per step: measured 2 % slower)
+            constexpr int AH = 2, RING = AH + 1;               // (two steps ahead: 309.5 -> 305.6 us once the registers were there;
+                                                               //  with 50 spilled registers it had been 2 % slower than one step)
             // vq[t] = LDS byte address of the lane's fragment of (chunk 0, stage q, part 0, column tile t); everything
             // else is a compile-time offset that fits the instruction's 16-bit field
             unsigned vq[MT];
