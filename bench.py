@@ -221,6 +221,79 @@ def gloo_rehearsal(args, rank, world):
         dist.destroy_process_group()
 
 
+def executed_mfma_flop(algo, conv_rows, conv_flop, cpl, n_cu):
+    """Flops the matrix pipe really executes per launch of the trunk kernel `algo` (goai_nn_conv_algo) over `conv_rows`
+    activation rows; conv_flop = the convolutions' own (algorithmic) flops of the launch."""
+    nb = int(round(conv_rows / (SIZE * SIZE)))
+    if algo == 2:
+        return 3.0 * conv_flop       # hi*hi + lo*hi + hi*lo on the bf16 pipe
+    if algo == 1:
+        # Winograd F(2x2,3x3): 16 products per 2x2 output tile and (cin, cout) instead of 36, on
+        # workgroups of 112 tile rows holding NBW whole boards (conv_wino_kernels.hip)
+        t2 = ((SIZE + 1) // 2) ** 2
+        wgs = -(-nb // (112 // t2))
+        rows = 100 if SIZE in (9, 13, 19) else 112       # six 16-row tiles + one round of 4x4 blocks, or seven tiles
+        return 2.0 * wgs * rows * 16 * 128 * 128
+    if algo in (6, 8):
+        # Winograd F(2x2,3x3) on the bf16 / fp16 pipe: workgroups of seven 16-column tiles (112 wtile rows), 16 positions,
+        # six bf16 (three fp16) products per transform-domain multiply-add
+        t2 = ((SIZE + 1) // 2) ** 2
+        wgs = -(-nb // (112 // t2))
+        return (6 if algo == 6 else 3) * 2.0 * wgs * 112 * 16 * 128 * 128
+    if algo in (5, 7):
+        # Winograd F(3x3,3x3) on the bf16 / fp16 pipe: 4 boards = 36 wtile rows run as three 16-column tiles
+        wgs = -(-nb // 4)
+        return (6 if algo == 5 else 3) * 2.0 * wgs * 48 * 25 * 128 * 128 * cpl
+    if algo in (3, 4):
+        # Winograd F(3x3,3x3): 25 products per 3x3 output tile; workgroups of 48 tile rows = 4 boards of 9x9
+        # (5 boards once 4 per workgroup would need more than one round of CUs)
+        wgs = -(-nb // 4) if -(-nb // 4) <= n_cu else -(-nb // 5)
+        # (the two-chunk kernel runs 32 rows as 16x16x4 tiles and the other 4 as 4x4x1 blocks: no padded rows)
+        return 2.0 * wgs * (36 if algo == 4 else 48) * 25 * 128 * 128 * cpl
+    return conv_flop
+
+
+KERNEL_NAMES = {0: "k_conv3x3", 1: "k_conv3x3_wino", 2: "k_conv3x3_bf16", 3: "k_conv3x3_wino3", 4: "k_conv3x3_wino3p",
+                5: "k_conv3x3_wino3s", 6: "k_conv3x3_wino2s", 7: "k_conv3x3_wino3s", 8: "k_conv3x3_wino2s"}
+
+
+def exact_fp32_record(cfg, args, n_games, rank, local_rank, n_cu):
+    """The same workload with GOAI_DTYPE_F32 (exact fp32 MFMA in every convolution), a few steps after the timed
+    region: the figure to hold next to `value` when the split-operand arithmetic is in question."""
+    import torch
+    from go_ai.game import BatchedSelfPlay
+    sp = BatchedSelfPlay(SIZE, n_games, SIMS, temp=1.0, device=local_rank, n_blocks=LAYERS, seed=1234,
+                         game_id_offset=rank * n_games, groups=args.groups, search=cfg["search"], dtype=0,
+                         refill=not args.no_refill)
+    sp.randomize_starts(cfg["random_moves"])
+    steps = max(2, min(args.steps, {"c2": 12, "c3": 2, "c4": 2, "c5": 1}[args.config]))
+    sp.play(2 if args.config == "c2" else 1)
+    e0 = sp.counters()["leaf_evals"]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sp.play(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    evals = sp.stats()["leaf_evals"] - e0
+    conv_ms, conv_n = sp.profile_conv()
+    cpl, algo = sp.ctx.nn_convs_per_launch(), sp.ctx.nn_conv_algo()
+    rec = {"dtype": "f32", "value": round(evals / dt, 1), "unit": "leaf evals/s", "steps": steps,
+           "ms_per_step": round(dt / steps * 1e3, 3), "kernel": KERNEL_NAMES[algo] + f"<{SIZE}>"}
+    if cfg["search"] == "ac" and conv_n:
+        rows = n_games // len(sp.groups) * SIZE * SIZE
+        flop = 2.0 * rows * 128 * (9 * 128) * cpl
+        launch_s = conv_ms / conv_n * 1e-3
+        ex = executed_mfma_flop(algo, rows, flop, cpl, n_cu)
+        rec.update({"avg_launch_us": round(launch_s * 1e6, 2), "convs_per_launch": cpl, "peak": PEAK_F32_MFMA_TFLOPS,
+                    "achieved": round(flop / launch_s / 1e12, 2), "frac": round(flop / launch_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                    "achieved_executed": round(ex / launch_s / 1e12, 2),
+                    "frac_executed": round(ex / launch_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                    "note": "frac = algorithmic flops over the fp32 MFMA peak; above 1 because Winograd executes 3.24x fewer "
+                            "products than the convolution has multiply-adds (frac_executed is the pipe's own fraction)"})
+    sp.close()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,7 +313,10 @@ def main():
                     help="leave the slot of a finished game idle instead of starting the next game in it")
     ap.add_argument("--c-gather", action="store_true",
                     help="also sum the per-rank results with the C-ABI's own RCCL all-reduce (goai_gather_stats) and "
-                         "check it against the torch.distributed gather")
+                         "check it against the torch.distributed gather (always on when more than one rank runs)")
+    ap.add_argument("--no-c-gather", action="store_true", help="N > 1: skip the C-ABI all-reduce cross-check")
+    ap.add_argument("--no-exact-fp32", action="store_true",
+                    help="skip the exact_fp32 sub-record (a few untimed-for-value steps of the same workload with --dtype f32)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: CPU rehearsal of the N-rank launch / rendezvous / gather path with a stub body (no GPU)")
     args = ap.parse_args()
@@ -318,44 +394,16 @@ def main():
     launch_s = conv_ms / conv_n * 1e-3
     peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     algo = sp.ctx.nn_conv_algo()
-    kname = {0: "k_conv3x3", 1: "k_conv3x3_wino", 2: "k_conv3x3_bf16", 3: "k_conv3x3_wino3", 4: "k_conv3x3_wino3p",
-             5: "k_conv3x3_wino3s", 6: "k_conv3x3_wino2s", 7: "k_conv3x3_wino3s", 8: "k_conv3x3_wino2s"}[algo] + f"<{SIZE}>"
-    executed_flop = conv_flop                 # flops the matrix pipe really executes per launch
-    if algo == 2:
-        executed_flop = 3.0 * conv_flop       # hi*hi + lo*hi + hi*lo on the bf16 pipe
-    elif algo == 1:
-        # Winograd F(2x2,3x3): 16 products per 2x2 output tile and (cin, cout) instead of 36, on
-        # workgroups of 112 tile rows holding NBW whole boards (conv_wino_kernels.hip)
-        t2 = ((SIZE + 1) // 2) ** 2
-        wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // (112 // t2))
-        rows = 100 if SIZE in (9, 13, 19) else 112       # six 16-row tiles + one round of 4x4 blocks, or seven tiles
-        executed_flop = 2.0 * wgs * rows * 16 * 128 * 128
-    elif algo in (6, 8):
-        # Winograd F(2x2,3x3) on the bf16 pipe: workgroups of seven 16-column tiles (112 wtile rows), 16 positions, six
-        # bf16 products per transform-domain multiply-add
-        t2 = ((SIZE + 1) // 2) ** 2
-        wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // (112 // t2))
-        executed_flop = (6 if algo == 6 else 3) * 2.0 * wgs * 112 * 16 * 128 * 128
-    elif algo in (5, 7):
-        # Winograd F(3x3,3x3) on the bf16 pipe: 4 boards = 36 wtile rows run as three 16-column tiles, six
-        # bf16 products (three-way split operands) per transform-domain multiply-add
-        wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // 4)
-        executed_flop = (6 if algo == 5 else 3) * 2.0 * wgs * 48 * 25 * 128 * 128 * cpl      # f16x3: three fp16 products on two-way splits
-    elif algo in (3, 4):
-        # Winograd F(3x3,3x3): 25 products per 3x3 output tile; workgroups of 48 tile rows = 4 boards of 9x9
-        # (5 boards once 4 per workgroup would need more than one round of CUs)
-        nb = int(round(conv_rows / (SIZE * SIZE)))
-        n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
-        wgs = -(-nb // 4) if -(-nb // 4) <= n_cu else -(-nb // 5)
-        # (the two-chunk kernel runs 32 rows as 16x16x4 tiles and the other 4 as 4x4x1 blocks: no padded rows)
-        executed_flop = 2.0 * wgs * (36 if algo == 4 else 48) * 25 * 128 * 128 * cpl
+    kname = KERNEL_NAMES[algo] + f"<{SIZE}>"
+    n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
+    executed_flop = executed_mfma_flop(algo, conv_rows, conv_flop, cpl, n_cu)
+    wgs = -(-int(round(conv_rows / (SIZE * SIZE))) // 4)
     lds_info = {}
     if algo == 7:
         # What this kernel really waits for besides instruction issue: LDS.  Per convolution and workgroup (DESIGN.md section 5,
         # profiles/r02_wino3s_ablation.txt): V fragment reads 50 stages x 8 waves x 6 tile steps x 2 parts x 1 KB = 4.8 MB, the
         # input transform's patch + table reads 1152 items x 1536 B = 1.77 MB, its V writes 1152 x 25 x 2 x 8 B = 0.46 MB,
         # image hand-over 0.17 MB; peak 128 B per clock and CU at 2.4 GHz.
-        n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
         lds_bytes = wgs * cpl * (4.8e6 + 1.77e6 + 0.46e6 + 0.17e6)
         lds_peak = n_cu * 128 * 2.4e9
         lds_info = {"lds": {"bytes_per_launch": lds_bytes, "achieved_TBps": round(lds_bytes / launch_s / 1e12, 2),
@@ -363,8 +411,8 @@ def main():
                             "note": "analytic LDS bytes of the launch at 128 B per clock and CU; SQ_LDS_IDX_ACTIVE measures 0.31 of the "
                                     "launch's CU cycles (profiles/r02_wino3s_ablation.txt).  Neither the matrix pipe nor LDS is what "
                                     "this kernel waits for: its SIMDs are bound by instruction issue (a stage = 36 MFMAs at 17 cycles + ~56 packed fmas at 4.9 + reads and loads, and MFMAs and vector instructions do not overlap: tools/ubench/mfma_f16_valu.hip)"}}
-    achieved = executed_flop / launch_s / 1e12           # TFLOP/s the matrix pipe sustains
-    effective = conv_flop / launch_s / 1e12              # the convolution's own flops per second (Winograd executes fewer)
+    executed = executed_flop / launch_s / 1e12           # TFLOP/s the matrix pipe sustains
+    achieved = conv_flop / launch_s / 1e12               # ALGORITHMIC: the convolutions' own flops per second (Winograd executes fewer)
 
     # the transition side (north_star subsystem 1): k_transition over 262,144 boards (the size of one Q-search
     # make_children step of 4096 games) taken from the games'
@@ -380,7 +428,7 @@ def main():
     total_evals, t_max = tot["leaf_evals"], tot["seconds"]
 
     c_gather = None
-    if args.c_gather and len(sp.groups) == 1:
+    if (args.c_gather or (world > 1 and not args.no_c_gather)) and len(sp.groups) == 1:
         # the same sums through goai_gather_stats: rank 0's RCCL id goes round by torch.distributed, the all-reduce is the library's
         ident = [sp.ctx.comm_unique_id() if rank == 0 else None]
         if world > 1:
@@ -390,6 +438,10 @@ def main():
         sp.ctx.comm_destroy(comm)
         assert int(extra[0]) == int(total_evals) and int(extra[1]) == int(tot["games"]), (extra, tot)
         c_gather = dict(sums, ranks=world, leaf_evals_timed=int(extra[0]), games=int(extra[1]))
+
+    exact = None
+    if rank == 0 and world == 1 and args.dtype != "f32" and not args.no_exact_fp32:
+        exact = exact_fp32_record(cfg, args, n_games, rank, local_rank, n_cu)
 
     if rank == 0:
         traffic, traffic_src = None, None
@@ -427,7 +479,9 @@ def main():
                        "weights": "random init, seed 0", "leaf_evals_timed": int(total_evals)},
             "roofline": {"bound": "mfma", "kernel": kname, **lds_info,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": round(achieved / peak, 4), "frac_algorithmic": round(achieved / peak, 4),
+                         "achieved_executed": round(executed, 2), "frac_executed": round(executed / peak, 4),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_us": round(launch_s * 1e6, 2), "launches_timed": conv_n,
                          "executed_mfma_flop_per_launch": executed_flop, "convs_per_launch": cpl,
                          "algorithm": {0: "direct implicit GEMM, fp32 MFMA", 1: "Winograd F(2x2,3x3), fp32 MFMA",
@@ -443,10 +497,12 @@ def main():
                                        8: "Winograd F(2x2,3x3), fp16 MFMA 16x16x32 on operands split into two fp16 parts and scaled by "
                                           "powers of two per board (3 products per multiply-add, fp32 accumulate, fp32 transforms): fp32-grade results"}[algo],
                          "algorithmic_flop_per_launch": conv_flop,
-                         "achieved_algorithmic": round(effective, 2),
-                         "note": "achieved / frac count the flops the matrix pipe executes; achieved_algorithmic counts the "
-                                 "convolutions' own 2*M*128*1152 flops per launch, which Winograd does with fewer products"},
+                         "achieved_algorithmic": round(achieved, 2),
+                         "note": "achieved / frac (= frac_algorithmic) count the convolutions' own 2*M*128*1152 flops per launch "
+                                 "(SURVEY.md 8d) over the HIP-event launch time; achieved_executed / frac_executed count the flops "
+                                 "the matrix pipe really executes (Winograd needs fewer products, the operand split three per product)"},
             "roofline_transition": tr,
+            **({"exact_fp32": exact} if exact else {}),
             "games": {"total": int(tot["games"]), "finished": int(tot["finished"]),
                       "black_wins": int(tot["black_wins"]), "white_wins": int(tot["white_wins"]),
                       "moves_played": int(tot["total_steps"])},

@@ -279,10 +279,13 @@ int goai_mcts_advance(goai_ctx* ctx, const int32_t* actions)
 
 int goai_mcts_set_active(goai_ctx* ctx, int n_active)
 {
-    GOAI_REQUIRE(ctx != nullptr && ctx->tree.n_games > 0, "call goai_mcts_init first");
+    CTX_ENTER(ctx);
+    GOAI_REQUIRE(ctx->tree.n_games > 0, "call goai_mcts_init first");
     GOAI_REQUIRE(n_active >= 1 && n_active <= ctx->tree.n_games, "n_active must be in [1, n_games]");
     ctx->tree.n_active = n_active;
     ctx->tree.steps_since_reset = -1;         // the roots must be set again
+    ctx->tree.pending_select = false;         // a half-done step of the old set is dropped with it
+    ctx->tree.pending_expand = 0;
     return GOAI_OK;
 }
 
@@ -325,12 +328,14 @@ int goai_mcts_game_stats(goai_ctx* ctx, int64_t* stats_host)
     CTX_ENTER(ctx);
     GOAI_REQUIRE(ctx->tree.steps_since_reset >= 0 && stats_host, "call goai_mcts_init and goai_mcts_reset first / NULL output");
     GOAI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    const size_t G = (size_t)ctx->tree.n_games;
+    const size_t G = (size_t)ctx->tree.n_games, active = (size_t)ctx->tree.n_active;
     std::vector<long long> slots(4 * G);
     GOAI_HIP_CHECK(hipMemcpy(slots.data(), ctx->tree.fin, slots.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    // totals "since the last goai_mcts_reset" of the ACTIVE slots: the reset clears exactly those, so a slot that
+    // goai_mcts_set_active left outside the set does not leak what it finished earlier
     for (int k = 0; k < 4; k++) {
         int64_t sum = 0;
-        for (size_t g = 0; g < G; g++) sum += slots[k * G + g];
+        for (size_t g = 0; g < active; g++) sum += slots[k * G + g];
         stats_host[k] = sum;
     }
     return GOAI_OK;

@@ -113,9 +113,12 @@ int gather_stats(goai_ctx* c, void* comm, double* extra_inout_host, int n_extra,
     const void* src[2] = { t.fin, t.counters };
     for (int h = 0; h < 2; h++) {
         GOAI_HIP_CHECK(hipMemcpy(slots.data(), src[h], slots.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        // finished-game totals: the active slots only (goai_mcts_reset clears those; a slot outside the active set
+        // still holds what it finished before goai_mcts_set_active shrank the set); counters: every slot
+        const size_t upto = h == 0 ? (size_t)t.n_active : G;
         for (int k = 0; k < 4; k++) {
             int64_t sum = 0;
-            for (size_t g = 0; g < G; g++) sum += slots[k * G + g];
+            for (size_t g = 0; g < upto; g++) sum += slots[k * G + g];
             totals_host[4 * h + k] = sum;
         }
     }

@@ -29,6 +29,14 @@ struct Tree {
     double* nval = nullptr;      // Q mode: node.val (tree.py:122-126), the critic's value of the node's state
     double* accR = nullptr;      // [..][8] lane accumulators of numpy's pairwise sum over full blocks of 8
     double* accT = nullptr;      // [..][8] pending tail (visits % 8 entries)
+    // max_sims > 128 only (else NULL): every visited node keeps its tanh'ed values in order, because numpy's pairwise sum of
+    // more than 128 values splits at n/2 - (n/2) % 8, a point that moves as the list grows (no incremental form).  A node
+    // takes log slot s = the number of nodes visited before it in this search; at most one node is first visited per
+    // step, so slot s starts at step >= s and holds at most M - s values (M = max_sims + 1 steps): slot s lives at
+    // vlog[g * M (M + 1) / 2 + s M - s (s - 1) / 2 ...].
+    double* vlog = nullptr;
+    int32_t* logof = nullptr;    // [..] a visited node's log slot
+    int32_t* nlog = nullptr;     // [G] slots handed out in this search
     double* rawsum = nullptr;    // sum of node.post_vals as backed up (raw values, not tanh): only str(node)'s "AV" reads it
     // rows: [G][rcap][A]
     double* prior = nullptr;

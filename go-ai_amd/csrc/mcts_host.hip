@@ -43,8 +43,9 @@ int mcts_init(goai_ctx* c, int n_games, int max_sims, int mode)
 static int mcts_init_impl(goai_ctx* c, int n_games, int max_sims, int mode)
 {
     GOAI_REQUIRE(n_games > 0, "n_games must be positive");
-    // numpy's pairwise mean is maintained incrementally for up to 128 values per node
-    GOAI_REQUIRE(max_sims >= 0 && max_sims <= 128, "max_sims must be in [0, 128]");
+    // numpy's pairwise mean is maintained incrementally for up to 128 values per node; beyond that every visited node keeps
+    // its value list (Tree::vlog, (max_sims + 1)(max_sims + 2) / 2 doubles per game)
+    GOAI_REQUIRE(max_sims >= 0 && max_sims <= GOAI_MAX_SIMS, "max_sims must be in [0, GOAI_MAX_SIMS = 2048]");
     GOAI_REQUIRE(mode == GOAI_SEARCH_AC || mode == GOAI_SEARCH_Q, "mode must be GOAI_SEARCH_AC or GOAI_SEARCH_Q");
     Tree& t = c->tree;
     t.max_sims = max_sims;
@@ -58,6 +59,10 @@ static int mcts_init_impl(goai_ctx* c, int n_games, int max_sims, int mode)
     AL(st, N * state_words(c->S));
     AL(parent, N); AL(pact, N); AL(visits, N); AL(rowof, N);
     AL(accR, N * 8); AL(accT, N * 8); AL(rawsum, N);
+    if (max_sims > 128) {
+        const size_t M = (size_t)max_sims + 1;
+        AL(vlog, G * (M * (M + 1) / 2)); AL(logof, N); AL(nlog, G);
+    }
     AL(prior, R * A); AL(child, R * A); AL(crow, R * A); AL(cN, R * A); AL(cQ, R * A);
     AL(nnodes, G); AL(nrows, G); AL(leaf, G); AL(depth, G); AL(path, R);
     AL(turn, G); AL(moves, G); AL(result, G); AL(episode, G); AL(fin, 4 * G);
@@ -207,7 +212,8 @@ int mcts_steps(goai_ctx* c, int n_steps)
     // latency-bound chains and fusing them saves their hand-overs (C2, 1024 games: +1.2 %); with more games than that the
     // separate kernels fill the chip better than a workgroup that is half idle in its middle phase (C4 / C5: -2 %).
     const bool small_batch = t.n_active <= 6 * c->net.n_cu;
-    if (!no_fusion && small_batch && n_steps >= 2 && !t.pending_select && t.n_active <= c->net.max_batch && c->net.w0_split) {
+    // (k_post_forward carries the <= 128-value backup only: long searches keep the separate launches)
+    if (!no_fusion && small_batch && !t.vlog && n_steps >= 2 && !t.pending_select && t.n_active <= c->net.max_batch && c->net.w0_split) {
         float* x = nullptr;
         bool x_is_h = false;                    // x = the heads' 1x1 convolutions, formed by the trunk launch (nn_host.hip)
         if ((rc = mcts_select(c, nullptr))) return rc;

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(64) void k_mcts_reset(Tree t, const uint8_t* __rest
         t.rowof[nb] = -1;
         t.nnodes[g] = 1;
         t.nrows[g] = 0;
+        if (t.nlog) t.nlog[g] = 0;
         t.turn[g] = player;
         t.moves[g] = 0;
         t.result[g] = (flags & FLAG_DONE) ? (player ? -sign : sign) : 2;
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(Tree t, uint8_t* __restrict_
 // Node.backprop (/root/reference/go_ai/search/tree.py:141-146) for the selected leaf of game g:
 // every node on the path gets tanh(value) with alternating sign appended to its running
 // numpy-pairwise mean, one lane per ancestor; the parent's PUCT inputs (cN, cQ) are refreshed.
-template <int S>
+template <int S, bool LONG = false>
 __device__ __forceinline__ void backprop_path(const Tree& t, int g, double v)
 {
     using G = Geom<S>;
@@ -254,14 +255,32 @@ __device__ __forceinline__ void backprop_path(const Tree& t, int g, double v)
             else { for (int i = 0; i < 8; i++) R[i] += Tl[i]; }
         }
         t.visits[xi] = n1;
+        const double* log = nullptr;
+        if (LONG) {
+            // the node's whole value list (max_sims > 128): only the leaf (j == 0, lane 0) can be on its first visit
+            const size_t M = (size_t)t.max_sims + 1;
+            int slot;
+            if (n == 0) {
+                slot = t.nlog[g];
+                t.nlog[g] = slot + 1;
+                t.logof[xi] = slot;
+            } else {
+                slot = t.logof[xi];
+            }
+            double* lg = t.vlog + (size_t)g * (M * (M + 1) / 2) + (size_t)slot * M - (size_t)slot * (slot - 1) / 2;
+            lg[n] = tv;
+            log = lg;
+        }
         if (X != 0) {
             double res;
             if (n1 < 8) {
                 res = 0.0;
                 for (int i = 0; i < n1; i++) res += Tl[i];
-            } else {
+            } else if (!LONG || n1 <= 128) {
                 res = ((R[0] + R[1]) + (R[2] + R[3])) + ((R[4] + R[5]) + (R[6] + R[7]));
                 for (int i = 0; i < (n1 & 7); i++) res += Tl[i];
+            } else {
+                res = np_pairwise_sum(log, n1);        // numpy's recursion over the halves (tree.py:180, any length)
             }
             const double mean = res / (double)n1;
             const size_t prow = (rb + t.rowof[nb + t.parent[xi]]) * G::A + t.pact[xi];
@@ -276,7 +295,7 @@ __device__ __forceinline__ void backprop_path(const Tree& t, int g, double v)
 // "fed the reference's NN outputs" mode of the parity tests.  With `raw` set the logits are
 // straight from the network and RLNet._numpy's post-processing
 // (/root/reference/go_ai/models/__init__.py:90-105) is fused in here.
-template <int S>
+template <int S, bool LONG = false>
 __device__ __forceinline__ void backup_game(const Tree& t, int g, const float* __restrict__ pi_logits,
                                             const float* __restrict__ prior_in, const float* __restrict__ val_in, int raw)
 {
@@ -290,7 +309,7 @@ __device__ __forceinline__ void backup_game(const Tree& t, int g, const float* _
     const int sign = meta_sign(meta);
     float v = val_in[g];
     if (raw && done) v = (float)(100 * sign);
-    backprop_path<S>(t, g, v);
+    backprop_path<S, LONG>(t, g, v);
 
     const int lrow = t.rowof[nb + leaf];
     if (done || lrow < 0) return;
@@ -346,12 +365,12 @@ __device__ __forceinline__ void backup_game(const Tree& t, int g, const float* _
     }
 }
 
-template <int S>
+template <int S, bool LONG>
 __global__ __launch_bounds__(64) void k_mcts_backup(Tree t, const float* __restrict__ pi_logits,
                                                     const float* __restrict__ prior_in,
                                                     const float* __restrict__ val_in, int raw)
 {
-    backup_game<S>(t, blockIdx.x, pi_logits, prior_in, val_in, raw);
+    backup_game<S, LONG>(t, blockIdx.x, pi_logits, prior_in, val_in, raw);
 }
 
 // Between two trunk launches of the lock-step search (actor-critic mode, the context's own network): everything one
@@ -572,6 +591,7 @@ __global__ __launch_bounds__(64) void k_mcts_advance(Tree t, const int32_t* __re
         t.rowof[nb] = -1;
         t.nnodes[g] = 1;
         t.nrows[g] = 0;
+        if (t.nlog) t.nlog[g] = 0;
     }
 }
 
@@ -696,7 +716,7 @@ __global__ __launch_bounds__(64) void k_q_expand(Tree t, uint8_t* __restrict__ c
 // action a; the reference keeps val.item(), a Python float, tree.py:14-19).
 // raw != 0: values are straight from the network and RLNet._numpy's override for finished
 // states (/root/reference/go_ai/models/__init__.py:101-105) is applied here.
-template <int S>
+template <int S, bool LONG>
 __global__ __launch_bounds__(64) void k_q_backup(Tree t, const double* __restrict__ leaf_val,
                                                  const double* __restrict__ child_vals_padded, int raw)
 {
@@ -710,7 +730,7 @@ __global__ __launch_bounds__(64) void k_q_backup(Tree t, const double* __restric
     const int off = t.q_off[g];
     double v = leaf_val ? leaf_val[g] : (double)t.q_vals[off];
     if (raw && done) v = (double)(100 * meta_sign(meta));
-    backprop_path<S>(t, g, v);
+    backprop_path<S, LONG>(t, g, v);
 
     const int lrow = t.rowof[nb + leaf];
     if (done || lrow < 0) return;
@@ -936,7 +956,13 @@ int launch_post_forward(int S_rt, const Tree& t, const float* act, const HeadWei
 int launch_mcts_backup(int S_rt, const Tree& t, const float* pi_logits, const float* prior, const float* val, int raw,
                        hipStream_t st)
 {
-    LAUNCH_PER_GAME(k_mcts_backup, t, pi_logits, prior, val, raw);
+    if (t.vlog) {
+        GOAI_DISPATCH_SIZE(S_rt, (k_mcts_backup<S, true><<<dim3(t.n_active), dim3(64), 0, st>>>(t, pi_logits, prior, val, raw)));
+    } else {
+        GOAI_DISPATCH_SIZE(S_rt, (k_mcts_backup<S, false><<<dim3(t.n_active), dim3(64), 0, st>>>(t, pi_logits, prior, val, raw)));
+    }
+    GOAI_HIP_CHECK(hipGetLastError());
+    return GOAI_OK;
 }
 int launch_mcts_readout(int S_rt, const Tree& t, int32_t* visits, double* prior, int32_t* root_visits, hipStream_t st)
 {
@@ -993,7 +1019,13 @@ int launch_q_expand(int S_rt, const Tree& t, uint8_t* children_out, uint8_t* val
 }
 int launch_q_backup(int S_rt, const Tree& t, const double* leaf_val, const double* child_vals_padded, int raw, hipStream_t st)
 {
-    LAUNCH_PER_GAME(k_q_backup, t, leaf_val, child_vals_padded, raw);
+    if (t.vlog) {
+        GOAI_DISPATCH_SIZE(S_rt, (k_q_backup<S, true><<<dim3(t.n_active), dim3(64), 0, st>>>(t, leaf_val, child_vals_padded, raw)));
+    } else {
+        GOAI_DISPATCH_SIZE(S_rt, (k_q_backup<S, false><<<dim3(t.n_active), dim3(64), 0, st>>>(t, leaf_val, child_vals_padded, raw)));
+    }
+    GOAI_HIP_CHECK(hipGetLastError());
+    return GOAI_OK;
 }
 int launch_q_child_values(int S_rt, const Tree& t, double* inv_vals, hipStream_t st)
 {

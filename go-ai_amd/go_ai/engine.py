@@ -47,6 +47,10 @@ class Context:
             _hip.lib.goai_ctx_destroy(self._h)
             self._h = None
 
+    @property
+    def closed(self):
+        return getattr(self, "_h", None) is None
+
     def __del__(self):
         try:
             self.close()
@@ -63,6 +67,9 @@ class Context:
         never hands a block back while a kernel of this context still reads it.  When the current stream
         differs from the one the context last used (a `with torch.cuda.stream(...)` block), the old
         stream is drained first, so the context's own device state (trees, activations) stays ordered."""
+        if self._h is None:
+            raise RuntimeError("this go_ai.engine.Context was closed (evicted from a context cache, or close() was called): "
+                               "its device state is gone")
         cur = torch.cuda.current_stream(self.device)
         if cur.cuda_stream != self._stream.cuda_stream:
             self._stream.synchronize()

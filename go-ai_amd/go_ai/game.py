@@ -232,6 +232,13 @@ class BatchedSelfPlay:
         for _ in range(n_moves):
             self.move()
 
+    def close(self):
+        """Release the groups' contexts (trees, activations, weights)."""
+        self.sync()
+        for c, _, _ in self.groups:
+            c.close()
+        self.groups = []
+
     def counters(self):
         tot = dict(leaf_evals=0, transitions=0, errors=0, forwards=0)
         for c, _ in self._each():

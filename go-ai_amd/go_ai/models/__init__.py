@@ -59,7 +59,14 @@ def average_model(comm, model):
     if world_size == 1:
         return
     flat = model.flat_parameters()
-    comm.allreduce(flat)
+    # data.TorchComm sums in place and returns its argument; mpi4py's lowercase allreduce (what the reference
+    # passes) and any comm with its semantics return a NEW object holding the sum and leave `flat` alone
+    summed = comm.allreduce(flat)
+    if summed is not None and summed is not flat:
+        summed = torch.as_tensor(summed)
+        if tuple(summed.shape) != tuple(flat.shape):
+            raise RuntimeError(f"average_model: comm.allreduce returned shape {tuple(summed.shape)}, expected {tuple(flat.shape)}")
+        flat.copy_(summed.to(device=flat.device, dtype=flat.dtype))
     flat.div_(world_size)
 
 
@@ -171,6 +178,18 @@ class RLNet:
             self._train.train_load(self._sd)
         return self
 
+    def _grow_train_batch(self, n):
+        """Training buffers for batches of up to n events.  An existing training context is rebuilt around the current
+        parameters and statistics; Adam's moments start again (as after a fresh torch.optim.Adam)."""
+        if self._train is not None:
+            import warnings
+            self._pull_trained()
+            self._train.close()
+            self._train = None
+            warnings.warn(f"go_ai.models: training batch capacity {self.train_batch} -> {n}: Adam's moments were reset",
+                          RuntimeWarning)
+        self.train_batch = int(n)
+
     def _tensor_shapes(self):
         return {k: tuple(v.shape) for k, v in self._sd.items() if not k.startswith("game_head.")}
 
@@ -196,6 +215,11 @@ class RLNet:
         self.train()
         children = np.asarray(children)
         bsz = len(children)
+        if bsz < 2:
+            raise ValueError(f"train_step: a batch of {bsz} event(s); BatchNorm needs at least 2")
+        if bsz > self.train_batch:
+            self._grow_train_batch(bsz)
+            self.train()
         next_states = children[np.arange(bsz), np.asarray(actions)]
         next_states = data.batch_random_symmetries(next_states)          # train_step's own
         next_states = data.batch_random_symmetries(next_states)          # critic_step's (models/__init__.py:119)
@@ -209,6 +233,16 @@ class RLNet:
         import warnings
         from ..data import SoloComm
         comm = comm if comm is not None else SoloComm()
+        # data.mpi_sample_eventdata's np.array_split hands out batches of up to 2 * batchsize - 1 events (and a
+        # single event when the replay is tiny): size the training buffers for the largest BEFORE any step moves the
+        # weights, and refuse what the step cannot take while the parameters are still untouched
+        batched_data = list(batched_data)
+        sizes = [len(batch[3]) for batch in batched_data]
+        if sizes and min(sizes) < 2:
+            raise ValueError(f"optimize: a batch of {min(sizes)} event(s); the optimisation step needs at least 2 "
+                             "(BatchNorm over a batch); nothing was changed")
+        if sizes and max(sizes) > self.train_batch:
+            self._grow_train_batch(max(sizes))
         self.train()
         raw_metrics = [self.train_step(optimizer, *batch) for batch in batched_data]
         average_model(comm, self)

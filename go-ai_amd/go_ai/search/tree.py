@@ -139,6 +139,9 @@ class RootView(Node):
             if self._ctx is None:                     # a root without a tree behind it (mcts = 0 helpers)
                 self._children = np.empty(self.actionsize(), dtype=object)
             else:
+                if self._ctx.closed:
+                    raise RuntimeError("the context that held this search tree was closed (evicted by later searches of "
+                                       "other shapes); read child_nodes (or call load()) right after the search")
                 if self._ctx.search_generation != self._gen:
                     raise RuntimeError("this search tree was overwritten by a later search on the same context; "
                                        "read child_nodes (or call load()) before searching again")

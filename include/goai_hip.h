@@ -178,8 +178,12 @@ int goai_nn_forward_static(goai_ctx* ctx, const uint8_t* states, float* pi_logit
 #define GOAI_SEARCH_Q 1    /* mct_search(go_env, n, critic=f): Q-value search, mct.py:27-30,43-47 */
 
 /* Allocate tree storage for n_games games and at most max_sims searches per move
- * (max_sims <= 128: numpy's pairwise mean of a node's values, tree.py:180, is maintained
- * incrementally up to 128 entries).  mode = GOAI_SEARCH_AC or GOAI_SEARCH_Q. */
+ * (0 <= max_sims <= GOAI_MAX_SIMS).  numpy's pairwise mean of a node's values (np.mean at
+ * tree.py:180) is maintained incrementally up to 128 entries; contexts with max_sims > 128 also keep
+ * every visited node's value list ((max_sims + 1)(max_sims + 2) / 2 doubles per game: 1.05 MB at
+ * 512) and sum it with numpy's own recursion -- bit-identical for any length.
+ * mode = GOAI_SEARCH_AC or GOAI_SEARCH_Q. */
+#define GOAI_MAX_SIMS 2048
 int goai_mcts_init(goai_ctx* ctx, int n_games, int max_sims, int mode);
 
 /* tree.Node(go_env.canonical_state()) for every game (mct.py:52-53): root_states is

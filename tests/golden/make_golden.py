@@ -420,8 +420,21 @@ def gen_train(kind, size, seed, B, steps=2):
     print("wrote", path, "metrics", [out[f"s{s}_metrics"] for s in range(steps)])
 
 
+def gen_long():
+    """Searches of more than 128 simulations: nodes on the principal line collect more than 128 values, where
+    np.mean's pairwise sum (tree.py:180) recurses over halves split at n/2 - (n/2) % 8."""
+    roots5 = [s.astype(np.float64) for s in random_positions(5, 6, 7, max_moves=18, canonical=False)]
+    roots5[0] = og.GoGame.get_init_board(5)
+    gen_mcts_ac("fake_peaky5_n300", 5, 300, roots5[:3], lambda i: fake_ac("peaky", np.random.default_rng(500 + i)))
+    gen_mcts_ac("fake_saturated5_n200", 5, 200, roots5[:2], lambda i: fake_ac("saturated", np.random.default_rng(520 + i)))
+    gen_mcts_q("fake_wide5_n150", 5, 150, roots5[:2], lambda i: fake_critic("wide", np.random.default_rng(540 + i)))
+
+
 def main():
     torch.manual_seed(0)
+    if "--only-long" in sys.argv:        # add the > 128-simulation fixtures without rewriting the others
+        gen_long()
+        return
     if "--only-train" in sys.argv:       # add the training fixtures without rewriting the others
         gen_train("ac", 5, 31, 16)
         gen_train("ac", 9, 32, 32)
@@ -477,6 +490,7 @@ def main():
     gen_mcts_q("fake_wide9_n20", 9, 20, roots9[:2], lambda i: fake_critic("wide", np.random.default_rng(400 + i)))
     gen_search_helpers()
     gen_temps()
+    gen_long()
     gen_train("ac", 5, 31, 16)
     gen_train("ac", 9, 32, 32)
     gen_train("val", 9, 33, 32)

@@ -125,3 +125,52 @@ def test_solo_comm_and_metrics_text():
     assert str(ModelMetrics(0.5, 0.25, 1.25, 0.5)) == "C[25.0% 0.500L] A[50.0% 1.250L] "
     opt = Adam(lr=2e-3)
     assert (opt.lr, opt.weight_decay) == (2e-3, 1e-4)
+
+
+class _FakeNet:
+    """Stands in for RLNet in average_model: a flat parameter tensor (CPU here, a GPU view in the product)."""
+
+    def __init__(self, values):
+        self.flat = torch.tensor(values, dtype=torch.float32)
+
+    def flat_parameters(self):
+        return self.flat
+
+
+class _ReturningComm:
+    """mpi4py semantics (what the reference passes, /root/reference/go_ai/models/__init__.py:279-282): lowercase
+    allreduce returns a NEW object with the sum and leaves its argument alone."""
+
+    def __init__(self, world, others):
+        self.world, self.others = world, others
+
+    def Get_size(self):
+        return self.world
+
+    def allreduce(self, x, op=None):
+        return (x.clone() + self.others).numpy()        # a new object, not even a tensor
+
+
+class _InPlaceComm(_ReturningComm):
+    """data.TorchComm semantics: sums in place, returns its argument."""
+
+    def allreduce(self, x, op=None):
+        x.add_(self.others)
+        return x
+
+
+class _InPlaceNoneComm(_ReturningComm):
+    def allreduce(self, x, op=None):
+        x.add_(self.others)
+
+
+@pytest.mark.parametrize("comm_cls", [_ReturningComm, _InPlaceComm, _InPlaceNoneComm])
+def test_average_model_uses_the_sum_the_communicator_returns(comm_cls):
+    sys.path.insert(0, os.path.join(ROOT, "go-ai_amd"))
+    from go_ai.models import average_model
+    net = _FakeNet([1.0, 2.0, 3.0])
+    average_model(comm_cls(2, torch.tensor([3.0, 2.0, 1.0])), net)
+    assert torch.equal(net.flat, torch.tensor([2.0, 2.0, 2.0]))
+    one = _FakeNet([5.0])
+    average_model(comm_cls(1, torch.tensor([100.0])), one)          # a single rank: untouched
+    assert torch.equal(one.flat, torch.tensor([5.0]))

@@ -19,7 +19,7 @@ def test_search_call_sequence_errors():
     with pytest.raises(_hip.GoaiError, match="mcts_init"):
         c.mcts_reset(np.zeros((1, 6, 5, 5), np.uint8))
     with pytest.raises(_hip.GoaiError, match="max_sims"):
-        c.mcts_init(2, 129)
+        c.mcts_init(2, 2049)             # GOAI_MAX_SIMS = 2048
     c.mcts_init(2, 3)
     with pytest.raises(_hip.GoaiError, match="already"):
         c.mcts_init(2, 3)
@@ -114,3 +114,57 @@ def test_failed_init_can_be_retried():
     c.mcts_run(3)
     assert int(c.mcts_readout()[0].sum()) == 4 * 3 and c.mcts_counters()["errors"] == 0
     c.close()
+
+
+def test_game_stats_count_the_active_slots_only():
+    """goai_mcts_game_stats / goai_gather_stats are totals 'since the last goai_mcts_reset' -- and that reset clears the
+    ACTIVE slots only.  Games finished while all slots were active must not show up after goai_mcts_set_active shrank
+    the set and the roots were reset."""
+    from go_ai.engine import Context
+    from helpers import from_ascii
+    size, n = 5, 8
+    root = from_ascii(["XX...", ".X...", "XX...", ".....", "....."], to_move=1, prev_pass=True).astype(np.uint8)
+    c = Context(size)
+    c.mcts_init(n, 2)
+    c.mcts_reset(np.repeat(root[None], n, 0))
+    c.mcts_advance(np.full(n, size * size, np.int32))       # second pass in a row: every game ends
+    assert c.mcts_game_stats()["finished"] == n
+    assert c.gather_stats(None)[0]["finished"] == n
+    c.mcts_set_active(3)
+    c.mcts_reset(np.repeat(root[None], 3, 0))
+    st = c.mcts_game_stats()
+    assert st == dict(finished=0, black_wins=0, white_wins=0, finished_moves=0), st
+    assert c.gather_stats(None)[0]["finished"] == 0
+    c.mcts_advance(np.full(3, size * size, np.int32))
+    assert c.mcts_game_stats()["finished"] == 3
+    # a half-done step does not survive a change of the active set
+    c.mcts_set_active(2)
+    c.mcts_reset(np.zeros((2, 6, size, size), np.uint8))
+    c.mcts_select()
+    c.mcts_set_active(2)
+    c.mcts_reset(np.zeros((2, 6, size, size), np.uint8))
+    c.mcts_select()                                         # would be "called twice" if the flag had survived
+    c.close()
+
+
+def test_closed_context_raises_clearly():
+    """Context caches (search/mct.py, RLNet.search_context) evict by close(); a tree view or a policy that still holds
+    the context must get a clear error, not a call on a dead handle."""
+    from go_ai.engine import Context
+    from go_ai.search.tree import RootView
+    c = Context(5)
+    c.mcts_init(1, 2)
+    c.mcts_reset(np.zeros((1, 6, 5, 5), np.uint8))
+    for _ in range(3):
+        c.mcts_select()
+        c.mcts_backup(np.zeros(1, np.float32), pi_logits=np.zeros((1, 26), np.float32))
+    visits, prior, root_visits = c.mcts_readout()
+    view = RootView(np.zeros((6, 5, 5)), visits[0].cpu().numpy(), prior[0].cpu().numpy(), int(root_visits[0]))
+    view.attach(c, 0)
+    c.close()
+    assert c.closed
+    with pytest.raises(RuntimeError, match="closed"):
+        view.child_nodes
+    with pytest.raises(RuntimeError, match="closed"):
+        c.mcts_readout()
+    c.close()                                               # closing twice is fine

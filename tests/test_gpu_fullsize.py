@@ -299,12 +299,12 @@ def test_c4_sampled_games_match_sequential_oracle(full_c4):
 # search is bit-exact whatever produced the logits; halves of the batch searched alone give bit-identical results
 # (a board's activation scale depends on that board alone).
 # =================================================================================================
-def _search_x6(size, games, sims, roots, offset=0, max_batch=None, dtype="f16x3"):
+def _search_x6(size, games, sims, roots, offset=0, max_batch=None, dtype="f16x3", layers=3):
     from go_ai.engine import Context
     from go_ai.models import random_state_dict
     c = Context(size)
-    c.nn_init(Context.NET_AC, 3, max_batch or games, dtype=Context.DTYPE_F16X3 if dtype == "f16x3" else Context.DTYPE_BF16X6)
-    c.load_weights(random_state_dict("ac", size, 0, 3))
+    c.nn_init(Context.NET_AC, layers, max_batch or games, dtype=Context.DTYPE_F16X3 if dtype == "f16x3" else Context.DTYPE_BF16X6)
+    c.load_weights(random_state_dict("ac", size, 0, layers))
     c.mcts_init(games, sims)
     c.mcts_reset(roots)
     c.mcts_run(sims)
@@ -315,12 +315,15 @@ def _search_x6(size, games, sims, roots, offset=0, max_batch=None, dtype="f16x3"
     return c, visits, prior, root_visits, pi.cpu().numpy(), acts, cnt
 
 
-@pytest.mark.parametrize("size,games,sims,random_moves,step,dtype", [
-    (9, 1024, 81, 40, 128, "f16x3"), (9, 1024, 81, 40, 256, "bf16x6"), (13, 8192, 81, 80, 2048, "f16x3")])
-def test_split_dtype_full_config_search(size, games, sims, random_moves, step, dtype):
+@pytest.mark.parametrize("size,games,sims,random_moves,step,dtype,layers", [
+    (9, 1024, 81, 40, 128, "f16x3", 3), (9, 1024, 81, 40, 256, "bf16x6", 3), (13, 8192, 81, 80, 2048, "f16x3", 3),
+    # BASELINE.json configs[4] at its full size (what `bench.py --config c5` runs): 19x19, 362 actions, the deeper CNN
+    # (10 blocks), 4096 concurrent games = a 4096-leaf batch per step, mid-game positions with large groups
+    (19, 4096, 81, 250, 1500, "f16x3", 10)])
+def test_split_dtype_full_config_search(size, games, sims, random_moves, step, dtype, layers):
     from go_ai.engine import Context
     roots = _roots_of(size, games, sims, random_moves, "ac")
-    c, visits, prior, root_visits, pi, acts, cnt = _search_x6(size, games, sims, roots, dtype=dtype)
+    c, visits, prior, root_visits, pi, acts, cnt = _search_x6(size, games, sims, roots, dtype=dtype, layers=layers)
     assert c.nn_conv_algo() == {("f16x3", True): Context.CONV_WINOGRAD_F3_F16X3, ("f16x3", False): Context.CONV_WINOGRAD_F16X3,
                                 ("bf16x6", True): Context.CONV_WINOGRAD_F3_BF16X6,
                                 ("bf16x6", False): Context.CONV_WINOGRAD_BF16X6}[(dtype, size == 9)]
@@ -341,6 +344,7 @@ def test_split_dtype_full_config_search(size, games, sims, random_moves, step, d
     for g in range(3, games, step):            # a sample of the games, replayed sequentially on the oracle
         env = GoEnv(size)
         env.state = st[g].astype(np.float64)
+        assert GoGame.valid_moves(st[g].astype(np.float64))[acts[g]] == 1        # legal on the oracle's rules too
         opi, counts, _ = mcts_ref.actor_critic_policy(env, net, sims, 1.0, math="det")
         assert np.array_equal(counts.astype(np.int32), visits[g]), f"game {g}"
         assert np.array_equal(opi, pi[g])
@@ -348,6 +352,7 @@ def test_split_dtype_full_config_search(size, games, sims, random_moves, step, d
     # two shards of half the games (what two GPUs would own): bit-identical searches and draws
     half = games // 2
     for lo in (0, half):
-        c2, v, p, _, q, a, _ = _search_x6(size, half, sims, roots[lo:lo + half], offset=lo, max_batch=games, dtype=dtype)
+        c2, v, p, _, q, a, _ = _search_x6(size, half, sims, roots[lo:lo + half], offset=lo, max_batch=games, dtype=dtype,
+                                          layers=layers)
         c2.close()
         assert np.array_equal(v, visits[lo:lo + half]) and np.array_equal(q, pi[lo:lo + half]) and np.array_equal(a, acts[lo:lo + half])

@@ -71,7 +71,10 @@ def test_replay_reference_search_fed_logits(name):
 
 @pytest.mark.parametrize("size,n_games,sims,layers", [(5, 24, 8, 3), (9, 16, 81, 3), (13, 4, 40, 3),
                                                       (19, 2, 30, 10),      # BASELINE.json configs[4]: 362 actions, deeper CNN
-                                                      (19, 3, 81, 3)])
+                                                      (19, 3, 81, 3),
+                                                      # more than 128 simulations: nodes with more than 128 values, whose
+                                                      # mean follows numpy's recursion over halves (Tree::vlog)
+                                                      (5, 6, 300, 3), (9, 3, 200, 3)])
 def test_full_search_matches_oracle(size, n_games, sims, layers):
     """GPU search with its own CNN vs the sequential oracle fed the same NN outputs."""
     from go_ai.engine import Context

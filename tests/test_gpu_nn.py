@@ -19,6 +19,8 @@ REL_TOL = 1e-3
 
 
 def rel_err(got, want):
+    """max |got - want| / max(|want|, 1): RELATIVE where |want| >= 1 and ABSOLUTE below it (logits of random-init nets
+    are O(0.1 .. 3), so for most entries this is the absolute error -- the stricter of the two readings there)."""
     got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
     return float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1.0)))
 
@@ -32,11 +34,23 @@ def make_ctx(kind, size, seed, layers=3, max_batch=256, dtype=0):
     return c, sd
 
 
+DTYPES = ["f32", "f16x3", "bf16x6"]
+
+
+def dtype_code(name):
+    from go_ai.engine import Context
+    return {"f32": Context.DTYPE_F32, "f16x3": Context.DTYPE_F16X3, "bf16x6": Context.DTYPE_BF16X6,
+            "bf16x3": Context.DTYPE_BF16X3}[name]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("name", ["nn_ac5", "nn_ac9", "nn_val9"])
-def test_forward_matches_reference_golden(name):
+def test_forward_matches_reference_golden(name, dtype):
+    """Fixtures recorded from the reference's own nn.Modules and RLNet._numpy (ac_net.py:40-45,
+    models/__init__.py:54-113) against every arithmetic the library offers -- f16x3 is what bench.py runs."""
     g = load_nn(name)
     kind, size, seed = str(g["kind"]), int(g["size"]), int(g["seed"])
-    c, sd = make_ctx(kind, size, seed)
+    c, sd = make_ctx(kind, size, seed, dtype=dtype_code(dtype))
     assert nn_ref.state_dict_digest(sd) == str(g["digest"])
     pi, val = c.nn_forward(g["states"], mode=c.NN_RAW)
     assert rel_err(val.cpu().numpy(), g["val_raw"]) < REL_TOL
@@ -148,9 +162,10 @@ def test_winograd_forward_matches_torch_oracle(kind, size, n, layers, max_batch,
     c.close()
 
 
-def test_numpy_shim_matches_oracle_on_special_states():
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_numpy_shim_matches_oracle_on_special_states(dtype):
     from oracle.gogame import GoGame
-    c, sd = make_ctx("ac", 5, 11)
+    c, sd = make_ctx("ac", 5, 11, dtype=dtype_code(dtype))
     base = random_positions(5, 12, seed=77, min_moves=8, canonical=True, pass_prob=0.0)
     sts = []
     for st in base:

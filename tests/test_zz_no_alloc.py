@@ -65,3 +65,29 @@ def test_static_forward_rejects_sizes_beyond_its_array():
     torch.cuda.synchronize()
     assert torch.isfinite(val[:n - 1]).all()
     c.close()
+
+
+@pytest.mark.parametrize("kind,size,layers,max_batch,n,dtype", [("ac", 9, 3, 1024, 101, 3), ("ac", 9, 3, 1024, 64, 0),
+                                                                 ("ac", 13, 3, 64, 48, 3), ("val", 9, 3, 16, 40, 3)])
+def test_static_forward_allocates_no_device_memory(kind, size, layers, max_batch, n, dtype):
+    """The property the entry point exists for: with the caller's inputs and outputs in place, a call leaves the
+    device's free memory where it was (hipMemGetInfo through torch.cuda.mem_get_info -- the driver's own figure, which
+    sees hipMalloc from any library, torch's caching allocator included).  Checked after one warm-up call, over several
+    calls in both output modes.  (HIP graph capture of the call is NOT tested here: the header only promises that the
+    call allocates nothing.)"""
+    c = _ctx(kind, size, layers, max_batch, dtype=dtype)
+    A = size * size + 1
+    st = torch.from_numpy(random_positions(size, n, seed=1, canonical=True, pass_prob=0.05)).to(c.device)
+    pi = torch.empty((n, A), dtype=torch.float32, device=c.device) if kind == "ac" else None
+    val = torch.empty((n, 1), dtype=torch.float32, device=c.device)
+    c.nn_forward_static(st, pi, val, mode=c.NN_RAW)           # warm-up: code objects loaded, lazy state set up
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(c.device)
+    reserved0 = torch.cuda.memory_reserved(c.device)
+    for mode in (c.NN_RAW, c.NN_NUMPY_SHIM, c.NN_RAW):
+        c.nn_forward_static(st, pi, val, mode=mode)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(c.device)
+    assert free1 == free0, (free0, free1)
+    assert torch.cuda.memory_reserved(c.device) == reserved0
+    c.close()
