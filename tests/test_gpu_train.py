@@ -250,7 +250,15 @@ def test_optimize_on_self_play_replay():
             _, wv = nn_ref.forward({k: v for k, v in got_sd.items()}, torch.from_numpy(cols[0][:8]), kind)
             ended = np.array([GoGame.game_ended(s) for s in cols[0][:8]], dtype=bool)
             assert np.allclose(after[~ended], wv.numpy()[~ended], rtol=1e-3, atol=1e-3)
-            with pytest.raises(Exception):                               # over train_batch
-                net.train_step(opt, *[np.concatenate([c, c]) for c in batches[0]])
+            # data.mpi_sample_eventdata's array_split hands out up to 2 * batchsize - 1 events: a batch over train_batch
+            # rebuilds the training buffers around the current parameters (Adam's moments restart, with a warning) ...
+            with pytest.warns(RuntimeWarning, match="capacity"):
+                out = net.train_step(opt, *[np.concatenate([c, c]) for c in batches[0]])
+            assert np.isfinite(out[0]) and net.train_batch == 2 * len(batches[0][0])
+            # ... and optimize() refuses a batch of one event before ANY step has moved the weights
+            held = {k: v.clone() for k, v in net.state_dict().items()}
+            with pytest.raises(ValueError, match="at least 2"):
+                net.optimize(data.SoloComm(), [batches[0], tuple(c[:1] for c in batches[1])], opt)
+            assert all(torch.equal(v, net.state_dict()[k]) for k, v in held.items())
     finally:
         GoGame.random_symmetry = real_sym
