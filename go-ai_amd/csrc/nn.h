@@ -38,6 +38,7 @@ struct Net {
     bool split6 = false;       // GOAI_DTYPE_BF16X6: F(3x3,3x3) with its products on the bf16 matrix cores, operands split in three
     void* wt_split6 = nullptr; // [2*layers][stages][8 waves][3 parts][64 lanes][8 bf16]: 100 stages for F(3x3,3x3) on 9x9
                                // (conv_wino3s_kernels.hip), 64 for F(2x2,3x3) on the other boards (conv_wino2s_kernels.hip)
+    bool wino3h = false;       // fp16 parts on 9x9: conv_wino3h_kernels.hip (GOAI_WINO3S_OLD=1: round 2's conv_wino3s_kernels.hip)
     int parts = 3;             // with split6: 3 bf16 parts per operand, or 2 fp16 parts (GOAI_DTYPE_F16X3: same kernels, same image
                                // with 2 parts, operands scaled by powers of two into fp16's range)
     int* wexp = nullptr;       // parts == 2: [2*layers] scale exponents of the weight images (device; wexp_host: the same)
@@ -91,6 +92,10 @@ int launch_conv3x3_wino3s(int S, float* x, float* y, const float* resid0, const 
                           const void* tab, int nboards, int n_convs, hipStream_t st, int parts = 3, const int* wexp = nullptr,
                           float* amax_io = nullptr, float amax_first = 0.0f, const float* head_w = nullptr,
                           const float* head_b = nullptr, float* head_out = nullptr);
+// round 3's form of the fp16 F(3x3,3x3) trunk (conv_wino3h_kernels.hip): parts = 2 (f16x3) or 1 (f16)
+int launch_conv3x3_wino3h(int S, float* x, float* y, const float* resid0, const void* wt_split, const float* bias, int nboards,
+                          int n_convs, hipStream_t st, int parts, const int* wexp, float* amax_io, float amax_first,
+                          const float* head_w = nullptr, const float* head_b = nullptr, float* head_out = nullptr);
 int launch_conv3x3_wino2s(int S, const float* in, const void* wt_split, const float* bias, const float* resid, float* out,
                           int nboards, hipStream_t st, int parts = 3, int wexp = 0, float* amax_io = nullptr,
                           float amax_first = 0.0f, const float* head_w = nullptr, const float* head_b = nullptr);

@@ -96,6 +96,7 @@ static int nn_init_impl(goai_ctx* c, int kind, int layers, int max_batch, int dt
             n.wino_mode = wino3_supported(c->S) ? 3 : 2;
             n.split6 = true;
             n.parts = dtype == GOAI_DTYPE_F16X3 ? 2 : 3;
+            n.wino3h = n.parts == 2 && n.wino_mode == 3 && !getenv("GOAI_WINO3S_OLD");
         }
         if (dtype == GOAI_DTYPE_F32) {
             if (algo && std::string(algo) == "wino") n.wino_mode = 2;
@@ -461,6 +462,10 @@ static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const f
         return launch_conv3x3_wino2s(c->S, in, (const uint16_t*)net.wt_split6 + (size_t)l * wt_split_per_conv(net), b, resid, out,
                                      M / c->P, c->stream, net.parts, net.wexp_host[l], net.amax, l == 0 ? net.amax0 : 0.0f,
                                      heads ? net.hw.conv_w : nullptr, net.hw.conv_b);
+    if (net.split6 && net.wino3h)
+        return launch_conv3x3_wino3h(c->S, const_cast<float*>(in), out, resid,
+                                     (const uint16_t*)net.wt_split6 + (size_t)l * wt_split_per_conv(net), b, M / c->P, 1, c->stream,
+                                     net.parts, net.wexp + l, net.amax, l == 0 ? net.amax0 : 0.0f);
     if (net.split6)
         return launch_conv3x3_wino3s(c->S, const_cast<float*>(in), out, resid,
                                      (const uint16_t*)net.wt_split6 + (size_t)l * wt_split_per_conv(net), b, net.wino3p_tab, M / c->P, 1,
@@ -513,7 +518,11 @@ static int nn_trunk_on(goai_ctx* c, float* const act[3], int nb, bool prof, floa
             c->prof_events.push_back(e1);
             GOAI_HIP_CHECK(hipEventRecord(e0, c->stream));
         }
-        rc = net.split6
+        rc = net.wino3h
+                 ? launch_conv3x3_wino3h(c->S, x, y, nullptr, net.wt_split6, net.bt, nb, 2 * net.layers, c->stream, net.parts, net.wexp,
+                                         nullptr, net.amax0, net.heads_in_trunk ? net.hw.conv_w : nullptr, net.hw.conv_b,
+                                         net.heads_in_trunk ? net.hbuf : nullptr)
+             : net.split6
                  ? launch_conv3x3_wino3s(c->S, x, y, nullptr, net.wt_split6, net.bt, net.wino3p_tab, nb, 2 * net.layers, c->stream,
                                          net.parts, net.wexp, nullptr, net.amax0, net.heads_in_trunk ? net.hw.conv_w : nullptr,
                                          net.hw.conv_b, net.heads_in_trunk ? net.hbuf : nullptr)
