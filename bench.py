@@ -234,6 +234,10 @@ def executed_mfma_flop(algo, conv_rows, conv_flop, cpl, n_cu):
         wgs = -(-nb // (112 // t2))
         rows = 100 if SIZE in (9, 13, 19) else 112       # six 16-row tiles + one round of 4x4 blocks, or seven tiles
         return 2.0 * wgs * rows * 16 * 128 * 128
+    if algo in (9, 10):        # one fp16 product per transform-domain multiply-add
+        t2 = ((SIZE + 1) // 2) ** 2
+        wgs = -(-nb // 4) if algo == 9 else -(-nb // (112 // t2))
+        return 2.0 * wgs * (48 * 25 * cpl if algo == 9 else 112 * 16) * 128 * 128
     if algo in (6, 8):
         # Winograd F(2x2,3x3) on the bf16 / fp16 pipe: workgroups of seven 16-column tiles (112 wtile rows), 16 positions,
         # six bf16 (three fp16) products per transform-domain multiply-add
@@ -254,7 +258,8 @@ def executed_mfma_flop(algo, conv_rows, conv_flop, cpl, n_cu):
 
 
 KERNEL_NAMES = {0: "k_conv3x3", 1: "k_conv3x3_wino", 2: "k_conv3x3_bf16", 3: "k_conv3x3_wino3", 4: "k_conv3x3_wino3p",
-                5: "k_conv3x3_wino3s", 6: "k_conv3x3_wino2s", 7: "k_conv3x3_wino3s", 8: "k_conv3x3_wino2s"}
+                5: "k_conv3x3_wino3s", 6: "k_conv3x3_wino2s", 7: "k_conv3x3_wino3h", 8: "k_conv3x3_wino2s",
+                9: "k_conv3x3_wino3h", 10: "k_conv3x3_wino2s"}
 
 
 def exact_fp32_record(cfg, args, n_games, rank, local_rank, n_cu):
@@ -303,11 +308,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--games", type=int, default=0, help="games per GPU (default: the config's)")
-    ap.add_argument("--dtype", choices=["auto", "f32", "bf16x3", "bf16x6", "f16x3"], default="auto",
+    ap.add_argument("--dtype", choices=["auto", "f32", "bf16x3", "bf16x6", "f16x3", "f16"], default="auto",
                     help="arithmetic of the trunk convolutions.  auto = f16x3 (fp16 matrix cores on operands split into two "
                          "fp16 parts and scaled by exact powers of two per board: fp32-grade results, error at the exact-fp32 "
                          "Winograd kernels' own level); bf16x6 = the same kernels with three bf16 parts and six products; "
-                         "f32 = exact fp32 MFMA everywhere; bf16x3 = two-part bf16 split (1e-5 class, opt-in)")
+                         "f32 = exact fp32 MFMA everywhere; bf16x3 = two-part bf16 split (1e-5 class, opt-in); f16 = ONE fp16 part per "
+                         "operand: REDUCED PRECISION (north_star's 1e-2 tier), its own line in profiles/, never the headline")
     ap.add_argument("--groups", type=int, default=1, help="independent game groups on separate HIP streams")
     ap.add_argument("--no-refill", action="store_true",
                     help="leave the slot of a finished game idle instead of starting the next game in it")
@@ -364,7 +370,7 @@ def main():
     n_games = args.games or cfg["games"]
     sp = BatchedSelfPlay(SIZE, n_games, SIMS, temp=1.0, device=local_rank, n_blocks=LAYERS, seed=1234,
                          game_id_offset=rank * n_games, groups=args.groups, search=cfg["search"],
-                         dtype={"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}[args.dtype], refill=not args.no_refill)
+                         dtype={"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3, "f16": 4}[args.dtype], refill=not args.no_refill)
     sp.randomize_starts(cfg["random_moves"])
     sp.play(args.warmup)
     cnt0 = sp.counters()
@@ -470,7 +476,10 @@ def main():
                           "f16x3": "fp32 storage; trunk products as 3 fp16 MFMAs on operands split into two fp16 parts (22 bits + sign), "
                                    "scaled by exact powers of two per board, fp32 accumulate and transforms; error vs the torch fp32 "
                                    "oracle at the exact-fp32 kernels' own level (tests/test_gpu_nn.py), tolerance 1e-3",
-                          "bf16x3": "fp32 storage; trunk products as 3 bf16 MFMAs on two-part splits: 2e-5..8e-5 vs torch fp32"}[args.dtype],
+                          "bf16x3": "fp32 storage; trunk products as 3 bf16 MFMAs on two-part splits: 2e-5..8e-5 vs torch fp32",
+                          "f16": "REDUCED PRECISION (opt-in, not the headline): fp32 storage; trunk products as ONE fp16 MFMA on operands "
+                                 "rounded to fp16 (11 bits) and scaled by powers of two per board; fp32 accumulate and transforms; "
+                                 "1e-3..4e-3 vs the torch fp32 oracle, tolerance 1e-2 (BASELINE.json north_star's second tier)"}[args.dtype],
             "config": {"workload": f"{cfg['name']}, {n_games} concurrent games per GPU, step = one move of every game "
                                    f"({SIMS + 1} leaf evals per game)",
                        "board": SIZE, "mcts": SIMS, "games_per_gpu": n_games, "parallelism": f"games sharded x{world}",
@@ -495,7 +504,9 @@ def main():
                                        7: "Winograd F(3x3,3x3), fp16 MFMA 16x16x32 on operands split into two fp16 parts and scaled by "
                                           "powers of two per board (3 products per multiply-add, fp32 accumulate, fp32 transforms): fp32-grade results",
                                        8: "Winograd F(2x2,3x3), fp16 MFMA 16x16x32 on operands split into two fp16 parts and scaled by "
-                                          "powers of two per board (3 products per multiply-add, fp32 accumulate, fp32 transforms): fp32-grade results"}[algo],
+                                          "powers of two per board (3 products per multiply-add, fp32 accumulate, fp32 transforms): fp32-grade results",
+                                       9: "Winograd F(3x3,3x3), ONE fp16 MFMA 16x16x32 per multiply-add on operands rounded to fp16 (reduced precision)",
+                                       10: "Winograd F(2x2,3x3), ONE fp16 MFMA 16x16x32 per multiply-add on operands rounded to fp16 (reduced precision)"}[algo],
                          "algorithmic_flop_per_launch": conv_flop,
                          "achieved_algorithmic": round(achieved, 2),
                          "note": "achieved / frac (= frac_algorithmic) count the convolutions' own 2*M*128*1152 flops per launch "

@@ -112,8 +112,9 @@ int goai_liberties(goai_ctx* ctx, const uint8_t* states, int32_t* black_libs, in
 int goai_nn_init(goai_ctx* ctx, int net_kind, int n_blocks, int max_batch, int dtype)
 {
     CTX_ENTER(ctx);
-    GOAI_REQUIRE(dtype == GOAI_DTYPE_F32 || dtype == GOAI_DTYPE_BF16X3 || dtype == GOAI_DTYPE_BF16X6 || dtype == GOAI_DTYPE_F16X3,
-                 "dtype must be GOAI_DTYPE_F32, GOAI_DTYPE_BF16X3, GOAI_DTYPE_BF16X6 or GOAI_DTYPE_F16X3");
+    GOAI_REQUIRE(dtype == GOAI_DTYPE_F32 || dtype == GOAI_DTYPE_BF16X3 || dtype == GOAI_DTYPE_BF16X6 || dtype == GOAI_DTYPE_F16X3 ||
+                     dtype == GOAI_DTYPE_F16,
+                 "dtype must be GOAI_DTYPE_F32, GOAI_DTYPE_BF16X3, GOAI_DTYPE_BF16X6, GOAI_DTYPE_F16X3 or GOAI_DTYPE_F16");
     return nn_init(ctx, net_kind, n_blocks, max_batch, dtype);
 }
 
@@ -129,6 +130,7 @@ int goai_nn_conv_algo(goai_ctx* ctx)
     GOAI_REQUIRE(ctx, "ctx is NULL");
     GOAI_REQUIRE(ctx->net.kind >= 0, "call goai_nn_init first");
     if (ctx->net.dtype == GOAI_DTYPE_BF16X3) return GOAI_CONV_BF16X3;
+    if (ctx->net.split6 && ctx->net.parts == 1) return ctx->net.wino_mode == 3 ? GOAI_CONV_WINOGRAD_F3_F16 : GOAI_CONV_WINOGRAD_F16;
     if (ctx->net.split6 && ctx->net.parts == 2) return ctx->net.wino_mode == 3 ? GOAI_CONV_WINOGRAD_F3_F16X3 : GOAI_CONV_WINOGRAD_F16X3;
     if (ctx->net.split6) return ctx->net.wino_mode == 3 ? GOAI_CONV_WINOGRAD_F3_BF16X6 : GOAI_CONV_WINOGRAD_BF16X6;
     if (ctx->net.wino_mode == 3) return ctx->net.wino3_paired ? GOAI_CONV_WINOGRAD_F3_PAIRED : GOAI_CONV_WINOGRAD_F3;

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     // V rows WT..ROWS-1 are never written: they stay zero and only reach accumulator columns that are never stored
     for (int i = tid; i < W::V_U4; i += 512) Vs[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
     if (tid < 8) Img[W::ZERO_U4 + tid] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-    if (NP == 2 && tid < 16) {
+    if (NP <= 2 && tid < 16) {
         const bool on = tid < W::NBW && b_first + tid < nboards;
         amax_in[tid] = __float_as_uint(!on ? 0.0f : amax_first > 0.0f ? amax_first : amax_io[b_first + tid]);
         amax_out[tid] = 0u;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
         for (int i = 0; i < W::NI; i++) {
             const int idx = tid + i * 512;
             if (idx < W::NBW * P * 8) {
-                if constexpr (NP == 2)
+                if constexpr (NP <= 2)
                     Img[w2s_swz(idx >> 3, idx & 7)] =
                         ireg[i] * __uint_as_float((unsigned)(127 + f16_scale_exp(amax_in[(idx >> 3) / P], 4)) << 23);
                 else
@@ -154,7 +154,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
             r[3] = s1 * img_at(t1.y >> 16) + s2 * img_at(t2.y >> 16);
             uint2* V = reinterpret_cast<uint2*>(Vs) + tw * 8 + ts;
             auto put = [&](int q, const f32x4 v) {
-                if constexpr (NP == 2) {
+                if constexpr (NP == 1) {
+                    V[q * (W::V_PART_U4 * 2)] = __builtin_bit_cast(uint2, __builtin_convertvector(v, f16x4));     // GOAI_DTYPE_F16: one part
+                } else if constexpr (NP == 2) {
                     // two fp16 parts, round to nearest: h = fp16(v), l = fp16(v - h) (the difference is exact in fp32)
                     // (l by v_fma_mixlo / mixhi_f16: reads h's halves in place, subtracts in fp32, writes a half register)
                     const uint2 hp = __builtin_bit_cast(uint2, __builtin_convertvector(v, f16x4));
@@ -249,7 +251,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
                         if (t + 1 < MT) v_read(q, t + 1, vf[(n + 1) & 1]);
                         else v_read(q < 3 ? q + 1 : 3, 0, vf[(n + 1) & 1]);          // (q == 3: a harmless re-read)
                         f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
-                        if constexpr (NP == 2) {
+                        if constexpr (NP == 1) {
+                            m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[qq][0]),
+                                                                          __builtin_bit_cast(f16x8, vf[n & 1][0]), acc, 0, 0, 0);
+                        } else if constexpr (NP == 2) {
                             const f16x8 u0 = __builtin_bit_cast(f16x8, wf[qq][0]), u1 = __builtin_bit_cast(f16x8, wf[qq][1]);
                             const f16x8 v0 = __builtin_bit_cast(f16x8, vf[n & 1][0]), v1 = __builtin_bit_cast(f16x8, vf[n & 1][1]);
                             // the three products of weight up to 2^-11, smallest first
@@ -337,12 +342,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
         for (int g = 0; g < GT; g++) {
             if (t0 + g >= MT) continue;
             // NP == 2: the accumulators are scaled back by 2^-(input scale of the tile's board + weight scale)
-            const int back = NP == 2 ? -(f16_scale_exp(amax_in[brd[g] < 0 ? 0 : brd[g]], 4) + wexp) : 0;
+            const int back = NP <= 2 ? -(f16_scale_exp(amax_in[brd[g] < 0 ? 0 : brd[g]], 4) + wexp) : 0;
             float mx = 0.0f;
 #pragma unroll
             for (int ij = 0; ij < 4; ij++) {
                 f32x4 v = Y[ij >> 1][ij & 1][t0 + g];
-                if constexpr (NP == 2) {
+                if constexpr (NP <= 2) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = __builtin_ldexpf(v[e], back);
                 }
@@ -358,10 +363,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
                             hp[lcell * 3 + c] = fmaf(v[3], hwv[c][3], fmaf(v[2], hwv[c][2], fmaf(v[1], hwv[c][1], v[0] * hwv[c][0])));
                     } else
                         *reinterpret_cast<f32x4*>(&out[off[g][ij]]) = v;
-                    if constexpr (NP == 2) mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+                    if constexpr (NP <= 2) mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
                 }
             }
-            if constexpr (NP == 2) {
+            if constexpr (NP <= 2) {
                 // the largest value stored for the tile's board: over the four lanes (lq) that hold the tile, then into LDS
                 mx = fmaxf(mx, __shfl_xor(mx, 16));
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
             }
         }
     }
-    if constexpr (NP == 2 && !HEADS) {
+    if constexpr (NP <= 2 && !HEADS) {
         __syncthreads();
         if (tid < W::NBW && b_first + tid < nboards) amax_io[b_first + tid] = __uint_as_float(amax_out[tid]);
     }
@@ -419,6 +424,14 @@ int launch_conv3x3_wino2s(int S_rt, const float* in, const void* wt_split, const
                           float* out, int nboards, hipStream_t st, int parts, int wexp, float* amax_io, float amax_first,
                           const float* head_w, const float* head_b)
 {
+    if (parts == 1) {
+        if (!amax_io) {
+            set_error("the fp16 F(2x2,3x3) convolution needs the boards' bounds (amax_io)");
+            return GOAI_ERR_ARG;
+        }
+        GOAI_DISPATCH_SIZE(S_rt, return (launch_wino2s_size<S, 1>(in, wt_split, bias, resid, out, nboards, st, wexp, amax_io, amax_first, head_w, head_b)));
+        return GOAI_OK;
+    }
     if (parts == 2) {
         if (!amax_io) {
             set_error("the fp16 F(2x2,3x3) convolution needs the boards' bounds (amax_io)");

@@ -91,12 +91,17 @@ static int nn_init_impl(goai_ctx* c, int kind, int layers, int max_batch, int dt
                 prop.multiProcessorCount > 0)
                 n.n_cu = prop.multiProcessorCount;
         }
-        if (dtype == GOAI_DTYPE_BF16X6 || dtype == GOAI_DTYPE_F16X3) {
+        if (dtype == GOAI_DTYPE_BF16X6 || dtype == GOAI_DTYPE_F16X3 || dtype == GOAI_DTYPE_F16) {
             // F(3x3,3x3) where it tiles the board exactly (9x9), F(2x2,3x3) elsewhere
             n.wino_mode = wino3_supported(c->S) ? 3 : 2;
+            // GOAI_DTYPE_F16 (one fp16 part, the 1e-2 tier): F(3x3,3x3)'s transforms (factors up to 4) amplify the operands'
+            // 2^-11 rounding to 1.1e-2 .. 1.4e-2 on the 3-block nets, F(2x2,3x3)'s to 2e-3 .. 6e-3: the tier runs F(2x2,3x3) on
+            // every board size; GOAI_F16_F3=1 keeps F(3x3,3x3) on 9x9 (faster, outside the tolerance: measurements only)
+            if (dtype == GOAI_DTYPE_F16 && !getenv("GOAI_F16_F3")) n.wino_mode = 2;
             n.split6 = true;
-            n.parts = dtype == GOAI_DTYPE_F16X3 ? 2 : 3;
-            n.wino3h = n.parts == 2 && n.wino_mode == 3 && !getenv("GOAI_WINO3S_OLD");
+            n.parts = dtype == GOAI_DTYPE_F16 ? 1 : dtype == GOAI_DTYPE_F16X3 ? 2 : 3;
+            // fp16 parts on 9x9: round 3's kernel (GOAI_WINO3S_OLD=1 keeps round 2's for the two-part form: A / B timing)
+            n.wino3h = n.wino_mode == 3 && (n.parts == 1 || (n.parts == 2 && !getenv("GOAI_WINO3S_OLD")));
         }
         if (dtype == GOAI_DTYPE_F32) {
             if (algo && std::string(algo) == "wino") n.wino_mode = 2;
@@ -131,7 +136,7 @@ static int nn_init_impl(goai_ctx* c, int kind, int layers, int max_batch, int dt
         }
         if (n.split6) {
             if ((rc = dev_alloc(c, &n.wt_split6, (size_t)2 * layers * wt_split_per_conv(n) * sizeof(uint16_t)))) return rc;
-            if (n.parts == 2) {
+            if (n.parts <= 2) {
                 if ((rc = dev_alloc(c, (void**)&n.wexp, (size_t)2 * layers * sizeof(int)))) return rc;
                 if ((rc = dev_alloc(c, (void**)&n.amax, (size_t)max_batch * sizeof(float)))) return rc;
             }
@@ -312,7 +317,7 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
                         }
                 }
             int wexp = 0;
-            if (parts == 2) {
+            if (parts <= 2) {
                 GOAI_REQUIRE(std::isfinite(umax), "non-finite convolution weights");
                 int ex = 0;
                 if (umax > 0.0f) std::frexp(umax, &ex);                        // umax in [2^(ex-1), 2^ex)
@@ -331,11 +336,11 @@ int nn_load_weights(goai_ctx* c, const char* const* names, const float* const* t
                             const size_t stage = (size_t)(chunk * T + pp) * T + qq;
                             const size_t lane = (size_t)(k / 8) * 16 + co % 16;
                             uint16_t* dst = &ws[(((stage * 8 + co / 16) * parts) * 64 + lane) * 8 + k % 8];
-                            if (parts == 2) {
+                            if (parts <= 2) {
                                 r = std::ldexp(r, wexp);
                                 const _Float16 h = (_Float16)r, lo = (_Float16)(r - (float)h);
                                 memcpy(dst, &h, 2);
-                                memcpy(dst + 64 * 8, &lo, 2);
+                                if (parts == 2) memcpy(dst + 64 * 8, &lo, 2);
                             } else
                                 for (int part = 0; part < 3; part++) {
                                     uint32_t bits;

@@ -122,7 +122,7 @@ class Context:
     NET_AC, NET_VAL = 0, 1
     NN_RAW, NN_NUMPY_SHIM = 0, 1
 
-    DTYPE_F32, DTYPE_BF16X3, DTYPE_BF16X6, DTYPE_F16X3 = 0, 1, 2, 3
+    DTYPE_F32, DTYPE_BF16X3, DTYPE_BF16X6, DTYPE_F16X3, DTYPE_F16 = 0, 1, 2, 3, 4      # DTYPE_F16: reduced precision, opt-in
 
     def nn_init(self, net_kind, n_blocks=3, max_batch=1024, dtype=0):
         self._bind()
@@ -131,6 +131,7 @@ class Context:
 
     CONV_DIRECT, CONV_WINOGRAD, CONV_BF16X3, CONV_WINOGRAD_F3, CONV_WINOGRAD_F3_PAIRED, CONV_WINOGRAD_F3_BF16X6, CONV_WINOGRAD_BF16X6 = 0, 1, 2, 3, 4, 5, 6
     CONV_WINOGRAD_F3_F16X3, CONV_WINOGRAD_F16X3 = 7, 8
+    CONV_WINOGRAD_F3_F16, CONV_WINOGRAD_F16 = 9, 10
 
     def nn_conv_algo(self):
         """The 3x3 convolution kernel nn_init chose for this context (CONV_*)."""

@@ -104,6 +104,11 @@ int goai_liberties(goai_ctx* ctx, const uint8_t* states, int32_t* black_libs, in
                              * a running upper bound).  Half the matrix work of GOAI_DTYPE_BF16X6 at the same measured
                              * accuracy: in both, the fp32 accumulation dominates the error (tests/test_gpu_nn.py,
                              * tools/ubench/f16x3_accuracy.hip). */
+#define GOAI_DTYPE_F16 4    /* REDUCED PRECISION, opt-in (BASELINE.json north_star's second tier: 1e-2 relative error; never what
+                             * bench.py's headline runs): the GOAI_DTYPE_F16X3 kernels with ONE fp16 part per operand and one
+                             * MFMA per product -- operands rounded to 11 significant bits (scaled per board / convolution as
+                             * above), fp32 accumulate, fp32 transforms, activations stored in fp32.  Measured 1e-3 .. 4e-3 on
+                             * the 3-block and 10-block nets (tests/test_gpu_nn.py::test_f16_forward_within_reduced_tolerance). */
 #define GOAI_NN_RAW 0       /* the nn.Module outputs (ac_net.forward / val_net.forward) */
 #define GOAI_NN_NUMPY_SHIM 1 /* + RLNet._numpy post-processing, models/__init__.py:90-105 */
 
@@ -128,6 +133,8 @@ int goai_nn_init(goai_ctx* ctx, int net_kind, int n_blocks, int max_batch, int d
 #define GOAI_CONV_WINOGRAD_BF16X6 6    /* GOAI_DTYPE_BF16X6 contexts, other boards: F(2x2,3x3) */
 #define GOAI_CONV_WINOGRAD_F3_F16X3 7  /* GOAI_DTYPE_F16X3 contexts, 9x9: F(3x3,3x3) */
 #define GOAI_CONV_WINOGRAD_F16X3 8     /* GOAI_DTYPE_F16X3 contexts, other boards: F(2x2,3x3) */
+#define GOAI_CONV_WINOGRAD_F3_F16 9    /* GOAI_DTYPE_F16 contexts, 9x9: F(3x3,3x3), one fp16 product */
+#define GOAI_CONV_WINOGRAD_F16 10      /* GOAI_DTYPE_F16 contexts, other boards: F(2x2,3x3), one fp16 product */
 int goai_nn_conv_algo(goai_ctx* ctx);
 
 /* How many of the trunk's 3x3 convolutions one kernel launch of this context runs (no reference
