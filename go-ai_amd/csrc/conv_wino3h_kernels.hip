@@ -128,7 +128,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3h(float* x, float* y, cons
     // main pass: wtile rem < 8 of board bl -> V row 8 bl + rem = 4 wave + t_g; tail pass (one wave): wtile 8 of board t_g -> V row 32 + t_g
     const int mrow = 4 * wave + t_g;
     const TItem it_main = t_item(mrow >> 3, mrow & 7, mrow), it_tail = t_item(t_g, 8, 32 + t_g);
-    constexpr int TAIL_WAVE = 7;
+#ifndef W3H_TAIL_WAVE
+#define W3H_TAIL_WAVE 7
+#endif
+    constexpr int TAIL_WAVE = W3H_TAIL_WAVE;
     const bool tail_wave = wave == TAIL_WAVE;
 
     f32x4 ireg[W::NI];

@@ -85,6 +85,29 @@ def test_transition_matches_oracle(ctxs, size, n):
             assert np.array_equal(got, want), name
 
 
+@pytest.mark.parametrize("size,n", [(9, 700), (19, 130)])
+def test_any_nonzero_byte_is_a_stone(ctxs, size, n):
+    """The boundary's uint8 planes: nonzero = set (np.asarray(state) != 0 is what the rules see).  The one-board-per-lane
+    kernels gather 0 / 1 bytes with dot products and redo a record that holds other values the general way: same
+    results whether a stone is written as 1, 255 or anything between, in a batch where only some records are odd."""
+    import torch
+    rng = np.random.default_rng(size)
+    states = random_positions(size, n, seed=50 + size, max_moves=int(1.2 * size * size), canonical=False)
+    acts = _random_actions(states, rng)
+    odd = states.copy()
+    scale = rng.integers(1, 256, size=odd.shape).astype(np.uint8)
+    scale[::3] = 1                                              # every third record stays 0 / 1
+    odd = (odd.astype(np.uint16) * scale).astype(np.uint8)
+    assert np.array_equal(odd != 0, states != 0) and odd.max() > 1
+    c = ctxs(size)
+    for canonical in (True, False):
+        want, wstatus = c.transition(states, acts, canonical=canonical)
+        got, gstatus = c.transition(torch.from_numpy(odd).cuda(), acts, canonical=canonical)
+        assert torch.equal(got, want) and torch.equal(gstatus, wstatus)
+    for a, b in zip(c.score(states), c.score(torch.from_numpy(odd).cuda())):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("size,n", [(5, 64), (9, 96), (13, 16), (19, 6)])
 def test_children_valid_win_match_oracle(ctxs, size, n):
     states = random_positions(size, n, seed=10 + size, max_moves=int(1.2 * size * size), canonical=True,
