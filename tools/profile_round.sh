@@ -12,7 +12,7 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for cfg in $CFGS; do
-    timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$cfg -- python3 $REPO/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${cfg}_bench_line.json 2> $OUT/${cfg}_stats.err
+    timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$cfg -- python3 $REPO/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-exact-fp32 > $OUT/${cfg}_bench_line.json 2> $OUT/${cfg}_stats.err
     cp $(find $OUT/stats_$cfg -name '*kernel_stats.csv' | head -1) $OUT/${cfg}_kernel_stats.csv
     echo "$cfg done"
 done
