@@ -172,7 +172,9 @@ int goai_nn_forward(goai_ctx* ctx, const uint8_t* states, float* pi_logits, floa
  * n * S * S <= GOAI_NN_STATIC_MAX_CELLS board cells (101 boards of 9x9, 48 of 13x13, 22 of 19x19);
  * larger n is rejected with GOAI_ERR_ARG.  All contexts of one GPU share the array and it keeps the
  * last call's contents (nothing in it has to start at zero): calls that overlap on one GPU --
- * different streams or host threads -- race; calls on one stream are ordered. */
+ * different streams or host threads -- race; calls on one stream are ordered.  (Tested: bit-equality with
+ * goai_nn_forward and that the device's free memory does not change across calls; capture into a HIP graph is
+ * what the entry point is for but is not itself under test.) */
 #define GOAI_NN_STATIC_MAX_CELLS 8192
 int goai_nn_forward_static(goai_ctx* ctx, const uint8_t* states, float* pi_logits, float* val_logits, int n,
                            int mode);
