@@ -10,9 +10,12 @@
 // transform rows p; per row one input-transform phase (all threads; Bt d B in fp32 on the vector ALUs, then
 // the three-way split) and 4 stages q of 7 tiles x 6 bf16 MFMAs (K = 32) per wave, each followed by the
 // fp32 output transform of its products.
-// LDS: IMG  one 32-channel chunk of the boards, fp32, [NBW * P cells + a zero cell][32 ch] (46 KB at 19x19)
+// LDS: IMG  one 32-channel chunk of the boards, fp32, ZERO-BORDERED since round 3 (as conv_wino3h_kernels.hip): rows of
+//           S + 2 cells = [x = -1][x = 0 .. S-1][x = S] (x = S + 1 is the next row's x = -1), a zero row above the first board
+//           and two below every board (a wtile's 4x4 patch spans y, x = -1 .. S + 1): a patch is one base address +
+//           immediates -- no address table, no table read in front of the patch reads, no per-read address arithmetic
+//           (59 KB at 13x13 and 19x19)
 //      V    [4 q][3 parts][112 rows][32 ch] bf16 = 86 KB, single-buffered
-//      Tab  16 cell addresses per wtile
 // Weights: [64 stages][8 waves][3 parts][64 lanes][8 bf16] per convolution (nn_host.hip), L2 -> registers one
 // stage ahead into alternating register sets; V fragments are read one tile ahead.
 //
@@ -38,26 +41,26 @@ struct Wino2S {
     static constexpr int MT = 7, ROWS = MT * 16;                   // wtile rows per workgroup
     static constexpr int NBW = ROWS / T2;                          // whole boards per workgroup
     static constexpr int WT = NBW * T2;                            // real wtiles per workgroup
-    static constexpr int IMG_U4 = NBW * P * 8 + 8;                 // in 16-byte units (+ the zero cell)
-    static constexpr int ZERO_U4 = NBW * P * 8;
+    static constexpr int ROWC = S + 2;                             // cells per image row
+    static constexpr int IMG_CELLS = (1 + NBW * (S + 2)) * ROWC + 1;
+    static constexpr int IMG_U4 = IMG_CELLS * 8;                   // in 16-byte units (a cell = 32 channels x 4 B)
+    // cell (y, x) of board b, y and x in -1 .. S + 1 (everything off the board is zero)
+    static constexpr int cell(int b, int y, int x) { return (1 + b * (S + 2) + y) * ROWC + x + 1; }
     static constexpr int V_PART_U4 = ROWS * 4;                     // one (q, part): [ROWS][32 ch] bf16 = 64 B per row
     static constexpr int V_U4 = 4 * NP * V_PART_U4;
-    static constexpr int TAB_U4 = WT * 2;                          // 16 x u16 LDS addresses per wtile
     static constexpr int NI = (NBW * P * 8 + 511) / 512;           // staged 16-byte pieces per thread per chunk
     static constexpr int AMAX_U4 = 8;                              // [2][16]: input / output bounds of the boards as fp32 bits (NP == 2)
     // HEADS: the heads' 1x1 convolutions of the output, [32 slots = (wave, lq)][NBW * P cells][3] fp32, over the dead image and V
     static constexpr int HP_U4 = (32 * NBW * P * 3 * 4 + 15) / 16;
     // (the bounds, which the epilogue still reads and collects, stay clear of it: they are the block's last 128 bytes)
-    static constexpr int WORK_U4 = IMG_U4 + V_U4 + TAB_U4 + AMAX_U4;
+    static constexpr int WORK_U4 = IMG_U4 + V_U4 + AMAX_U4;
     static constexpr int LDS_U4 = WORK_U4 > HP_U4 + AMAX_U4 ? WORK_U4 : HP_U4 + AMAX_U4;
     static_assert(LDS_U4 * 16 <= 160 * 1024, "LDS budget");
     static_assert(NBW <= 16, "bounds table");
     static_assert(NBW >= 1, "board too large for one workgroup");
     static_assert(LDS_U4 * 16 <= 160 * 1024, "LDS budget");
-    static_assert(IMG_U4 * 16 < 65536, "input-transform addresses are 16-bit");
 };
 
-__device__ __forceinline__ int w2s_swz(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
 // two fp32 bit patterns whose low halves are dropped -> one word of two bf16 (a in the low half)
 __device__ __forceinline__ unsigned w2s_pack(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
@@ -77,7 +80,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     __shared__ f32x4 lds[W::LDS_U4];
     f32x4* Img = lds;
     f32x4* Vs = lds + W::IMG_U4;
-    uint16_t* Tab = reinterpret_cast<uint16_t*>(lds + W::IMG_U4 + W::V_U4);
     unsigned* amax_in = reinterpret_cast<unsigned*>(lds + W::LDS_U4 - W::AMAX_U4);
     unsigned* amax_out = amax_in + 16;
 
@@ -86,24 +88,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     const int b_first = blockIdx.x * W::NBW;
 
     // V rows WT..ROWS-1 are never written: they stay zero and only reach accumulator columns that are never stored
-    for (int i = tid; i < W::V_U4; i += 512) Vs[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-    if (tid < 8) Img[W::ZERO_U4 + tid] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    // (and the image region: its border cells are never written)
+    for (int i = tid; i < W::IMG_U4 + W::V_U4; i += 512) lds[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
     if (NP <= 2 && tid < 16) {
         const bool on = tid < W::NBW && b_first + tid < nboards;
         amax_in[tid] = __float_as_uint(!on ? 0.0f : amax_first > 0.0f ? amax_first : amax_io[b_first + tid]);
         amax_out[tid] = 0u;
     }
-    // Tab[tw][a][b] = byte address in Img (slot 0, before the slot swizzle) of cell (2ty - 1 + a, 2tx - 1 + b) of
-    // wtile tw's 4x4 input patch, or of the zero cell when that is off the board
-    for (int e = tid; e < W::WT * 16; e += 512) {
-        const int tw = e >> 4, a = (e >> 2) & 3, b = e & 3;
-        const int bl = tw / W::T2, rem = tw - bl * W::T2;
-        const int ty = rem / W::T, tx = rem - ty * W::T;
-        const int y = 2 * ty - 1 + a, x = 2 * tx - 1 + b;
-        const bool ok = y >= 0 && y < S && x >= 0 && x < S;
-        Tab[e] = (uint16_t)((ok ? (bl * P + y * S + x) * 8 : W::ZERO_U4) * 16);
-    }
-
     const int ts = tid & 7;                           // 4-channel slot of this thread's input-transform items
     f32x4 ireg[W::NI];
     auto load_img = [&](int chunk) {
@@ -123,19 +114,27 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
         for (int i = 0; i < W::NI; i++) {
             const int idx = tid + i * 512;
             if (idx < W::NBW * P * 8) {
+                const int cr = idx >> 3, bl = cr / P, rem = cr - bl * P, yy = rem / S, xx = rem - yy * S;
+                f32x4* dst = &Img[W::cell(bl, yy, xx) * 8 + (idx & 7)];
                 if constexpr (NP <= 2)
-                    Img[w2s_swz(idx >> 3, idx & 7)] =
-                        ireg[i] * __uint_as_float((unsigned)(127 + f16_scale_exp(amax_in[(idx >> 3) / P], 4)) << 23);
+                    *dst = ireg[i] * __uint_as_float((unsigned)(127 + f16_scale_exp(amax_in[bl], 4)) << 23);
                 else
-                    Img[w2s_swz(idx >> 3, idx & 7)] = ireg[i];
+                    *dst = ireg[i];
             }
         }
     };
-    auto img_at = [&](uint32_t byte_addr) -> f32x4 {
-        const uint32_t cell = byte_addr >> 7;         // slot swizzle of w2s_swz() on a byte address
-        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Img) + byte_addr +
-                                               ((ts ^ ((cell >> 1) & 7)) << 4));
+    // patch cell (a, b) of the item whose cell (-1, -1) (+ its slot) is at byte address `base`
+    auto img_at = [&](uint32_t base, int a, int b) -> f32x4 {
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Img) + base + (a * W::ROWC + b) * 128);
     };
+    // this thread's two items (wtiles tid / 8 and tid / 8 + 64, slot ts): byte address of patch cell (-1, -1)
+    uint32_t tbase[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int tw = (tid >> 3) + 64 * j;
+        const int bl = tw / W::T2, rem = tw - bl * W::T2, ty = rem / W::T, tx = rem - ty * W::T;
+        tbase[j] = (uint32_t)(W::cell(tw < W::WT ? bl : 0, 2 * ty - 1, 2 * tx - 1) * 128 + ts * 16);
+    }
     // V[q][part][tw][ts] = the three bf16 parts of (Bt d B)[p][q], q = 0..3; rows of Bt are
     // (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
     auto transform = [&](int p) {
@@ -145,13 +144,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
         for (int j = 0; j < 2; j++) {
             const int tw = (tid >> 3) + 64 * j;
             if (tw >= W::WT) continue;
-            const uint2 t1 = *reinterpret_cast<const uint2*>(&Tab[tw * 16 + a1 * 4]);
-            const uint2 t2 = *reinterpret_cast<const uint2*>(&Tab[tw * 16 + a2 * 4]);
             f32x4 r[4];
-            r[0] = s1 * img_at(t1.x & 0xffffu) + s2 * img_at(t2.x & 0xffffu);
-            r[1] = s1 * img_at(t1.x >> 16) + s2 * img_at(t2.x >> 16);
-            r[2] = s1 * img_at(t1.y & 0xffffu) + s2 * img_at(t2.y & 0xffffu);
-            r[3] = s1 * img_at(t1.y >> 16) + s2 * img_at(t2.y >> 16);
+#pragma unroll
+            for (int b = 0; b < 4; b++) r[b] = s1 * img_at(tbase[j], a1, b) + s2 * img_at(tbase[j], a2, b);
             uint2* V = reinterpret_cast<uint2*>(Vs) + tw * 8 + ts;
             auto put = [&](int q, const f32x4 v) {
                 if constexpr (NP == 1) {
