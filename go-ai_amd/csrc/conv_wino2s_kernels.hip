@@ -14,7 +14,7 @@
 //           S + 2 cells = [x = -1][x = 0 .. S-1][x = S] (x = S + 1 is the next row's x = -1), a zero row above the first board
 //           and two below every board (a wtile's 4x4 patch spans y, x = -1 .. S + 1): a patch is one base address +
 //           immediates -- no address table, no table read in front of the patch reads, no per-read address arithmetic
-//           (59 KB at 13x13 and 19x19)
+//           (59 KB at 13x13 and 19x19); a cell's two 64-byte halves in two regions (Wino2S::HALF_B: conflict-free patch reads)
 //      V    [4 q][3 parts][112 rows][32 ch] bf16 = 86 KB, single-buffered
 // Weights: [64 stages][8 waves][3 parts][64 lanes][8 bf16] per convolution (nn_host.hip), L2 -> registers one
 // stage ahead into alternating register sets; V fragments are read one tile ahead.
@@ -43,7 +43,12 @@ struct Wino2S {
     static constexpr int WT = NBW * T2;                            // real wtiles per workgroup
     static constexpr int ROWC = S + 2;                             // cells per image row
     static constexpr int IMG_CELLS = (1 + NBW * (S + 2)) * ROWC + 1;
-    static constexpr int IMG_U4 = IMG_CELLS * 8;                   // in 16-byte units (a cell = 32 channels x 4 B)
+    // a cell's 32 channels x 4 B as two 64-byte halves (channel slots 0-3 | 4-7) in two regions HALF_B = 64 (mod 256) bytes
+    // apart: the lanes of a ds_read_b128 group ({0-3, 12-15, 20-27}, ...: halves of four consecutive wtiles, whose
+    // cells lie 2 apart) then touch all 64 banks once -- with whole 128-byte cells every patch read is a 2-way conflict
+    static constexpr int HALF_B = (IMG_CELLS * 64 + 255) / 256 * 256 + 64;
+    static constexpr int IMG_U4 = (HALF_B + IMG_CELLS * 64) / 16;  // in 16-byte units
+    static constexpr int slot_at(int cell, int slot) { return ((slot >> 2) * HALF_B + cell * 64 + (slot & 3) * 16) / 16; }
     // cell (y, x) of board b, y and x in -1 .. S + 1 (everything off the board is zero)
     static constexpr int cell(int b, int y, int x) { return (1 + b * (S + 2) + y) * ROWC + x + 1; }
     static constexpr int V_PART_U4 = ROWS * 4;                     // one (q, part): [ROWS][32 ch] bf16 = 64 B per row
@@ -53,13 +58,44 @@ struct Wino2S {
     // HEADS: the heads' 1x1 convolutions of the output, [32 slots = (wave, lq)][NBW * P cells][3] fp32, over the dead image and V
     static constexpr int HP_U4 = (32 * NBW * P * 3 * 4 + 15) / 16;
     // (the bounds, which the epilogue still reads and collects, stay clear of it: they are the block's last 128 bytes)
+    // epilogue: the area through which a tile's cells change lanes, per wave [2 tiles][4 cells][4 quads][17] x 16 B over
+    // the dead image and V -- or, with HEADS, [2 cells][4 quads][17] x 16 B behind the heads' area
+    static constexpr int XCH_WAVE_U4 = 2 * 4 * 72, XCH_HEADS_WAVE_U4 = 2 * 72;
     static constexpr int WORK_U4 = IMG_U4 + V_U4 + AMAX_U4;
-    static constexpr int LDS_U4 = WORK_U4 > HP_U4 + AMAX_U4 ? WORK_U4 : HP_U4 + AMAX_U4;
+    static constexpr int LDS_U4 = WORK_U4 > HP_U4 + 8 * XCH_HEADS_WAVE_U4 + AMAX_U4 ? WORK_U4 : HP_U4 + 8 * XCH_HEADS_WAVE_U4 + AMAX_U4;
+    static_assert(8 * XCH_WAVE_U4 + AMAX_U4 <= WORK_U4, "exchange area");
     static_assert(LDS_U4 * 16 <= 160 * 1024, "LDS budget");
     static_assert(NBW <= 16, "bounds table");
     static_assert(NBW >= 1, "board too large for one workgroup");
     static_assert(LDS_U4 * 16 <= 160 * 1024, "LDS budget");
 };
+
+#ifdef GOAI_CONV_STAMPS
+// diagnostic build only (tools/wino2s_stamps.py): s_memrealtime (100 MHz) stamps, 40 per workgroup: 0 top, 1 first image
+// staged, 2 + 2r V of row r complete (r = 4 chunk + p), 3 + 2r its four stages done, 34 epilogue done; 35 / 36 = s_memtime at 0 / 34; 37 / 38 epilogue: behind its first barrier / wave 0's last store issued
+__device__ unsigned long long g_wino2s_stamps[40 * 8192];
+extern "C" int goai_debug_wino2s_stamps(unsigned long long* host_out, int n)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino2s_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#define W2S_STAMP(i) if (RESID && !HEADS && threadIdx.x == 0 && blockIdx.x < 8192) { g_wino2s_stamps[blockIdx.x * 40 + (i)] = __builtin_amdgcn_s_memrealtime(); if ((i) == 0 || (i) == 34) g_wino2s_stamps[blockIdx.x * 40 + 35 + ((i) == 34)] = __builtin_amdgcn_s_memtime(); }
+#else
+#define W2S_STAMP(i)
+#endif
+#ifndef W2S_DIAG
+#define W2S_DIAG 0      // diagnostic builds only (wrong results): 1 no output transform, 2 no patch reads, 4 no residual loads,
+#endif                  // 8 one image only, 16 one weight set only, 32 no stores, 64 every workgroup's residual / output at the first boards' place
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned w2s_v4u __attribute__((vector_size(16)));
+// y -= m as two v_pk_fma_f32 by n1 = (-1, -1), a value the optimiser cannot see through: it turns a plain vector
+// subtraction (and a multiply-add by a visible -1.0) into four v_sub_f32 -- twice the issue slots.  fma(m, -1, y) = y - m exactly.
+__device__ __forceinline__ void w2s_sub4(f32x4& y, const f32x4 m, const f32x2 n1)
+{
+    const f32x2 lo = __builtin_elementwise_fma(__builtin_shufflevector(m, m, 0, 1), n1, __builtin_shufflevector(y, y, 0, 1));
+    const f32x2 hi = __builtin_elementwise_fma(__builtin_shufflevector(m, m, 2, 3), n1, __builtin_shufflevector(y, y, 2, 3));
+    y = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
 
 // two fp32 bit patterns whose low halves are dropped -> one word of two bf16 (a in the low half)
 __device__ __forceinline__ unsigned w2s_pack(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
@@ -86,6 +122,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int b_first = blockIdx.x * W::NBW;
+#ifdef W2S_STAGGER
+    // experiment: the first round's workgroups start W2S_STAGGER phases apart, so that the epilogues (the only HBM-heavy
+    // part) of the workgroups resident at any time do not coincide
+    if (blockIdx.x < 256)
+        for (int i = 0; i < (int)(blockIdx.x % W2S_STAGGER) * (20 / (W2S_STAGGER - 1) + 1); i++) __builtin_amdgcn_s_sleep(127);
+#endif
+    W2S_STAMP(0);
 
     // V rows WT..ROWS-1 are never written: they stay zero and only reach accumulator columns that are never stored
     // (and the image region: its border cells are never written)
@@ -95,6 +138,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
         amax_in[tid] = __float_as_uint(!on ? 0.0f : amax_first > 0.0f ? amax_first : amax_io[b_first + tid]);
         amax_out[tid] = 0u;
     }
+    f32x2 neg1 = { -1.0f, -1.0f };                    // (w2s_sub4)
+    asm volatile("" : "+v"(neg1));
     const int ts = tid & 7;                           // 4-channel slot of this thread's input-transform items
     f32x4 ireg[W::NI];
     auto load_img = [&](int chunk) {
@@ -115,7 +160,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
             const int idx = tid + i * 512;
             if (idx < W::NBW * P * 8) {
                 const int cr = idx >> 3, bl = cr / P, rem = cr - bl * P, yy = rem / S, xx = rem - yy * S;
-                f32x4* dst = &Img[W::cell(bl, yy, xx) * 8 + (idx & 7)];
+                f32x4* dst = &Img[W::slot_at(W::cell(bl, yy, xx), idx & 7)];
                 if constexpr (NP <= 2)
                     *dst = ireg[i] * __uint_as_float((unsigned)(127 + f16_scale_exp(amax_in[bl], 4)) << 23);
                 else
@@ -125,7 +170,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     };
     // patch cell (a, b) of the item whose cell (-1, -1) (+ its slot) is at byte address `base`
     auto img_at = [&](uint32_t base, int a, int b) -> f32x4 {
-        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Img) + base + (a * W::ROWC + b) * 128);
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Img) + base + (a * W::ROWC + b) * 64);
     };
     // this thread's two items (wtiles tid / 8 and tid / 8 + 64, slot ts): byte address of patch cell (-1, -1)
     uint32_t tbase[2];
@@ -133,7 +178,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     for (int j = 0; j < 2; j++) {
         const int tw = (tid >> 3) + 64 * j;
         const int bl = tw / W::T2, rem = tw - bl * W::T2, ty = rem / W::T, tx = rem - ty * W::T;
-        tbase[j] = (uint32_t)(W::cell(tw < W::WT ? bl : 0, 2 * ty - 1, 2 * tx - 1) * 128 + ts * 16);
+        tbase[j] = (uint32_t)(W::slot_at(W::cell(tw < W::WT ? bl : 0, 2 * ty - 1, 2 * tx - 1), ts) * 16);
     }
     // V[q][part][tw][ts] = the three bf16 parts of (Bt d B)[p][q], q = 0..3; rows of Bt are
     // (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
@@ -146,7 +191,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
             if (tw >= W::WT) continue;
             f32x4 r[4];
 #pragma unroll
-            for (int b = 0; b < 4; b++) r[b] = s1 * img_at(tbase[j], a1, b) + s2 * img_at(tbase[j], a2, b);
+            for (int b = 0; b < 4; b++) {
+                if (W2S_DIAG & 2) r[b] = f32x4{ (float)tbase[j], (float)b, (float)p, s1 };
+                else if (s1 > 0.0f && s2 > 0.0f) r[b] = img_at(tbase[j], a1, b) + img_at(tbase[j], a2, b);
+                else if (s1 > 0.0f) { r[b] = img_at(tbase[j], a1, b); w2s_sub4(r[b], img_at(tbase[j], a2, b), neg1); }
+                else { r[b] = img_at(tbase[j], a2, b); w2s_sub4(r[b], img_at(tbase[j], a1, b), neg1); }
+            }
             uint2* V = reinterpret_cast<uint2*>(Vs) + tw * 8 + ts;
             auto put = [&](int q, const f32x4 v) {
                 if constexpr (NP == 1) {
@@ -178,10 +228,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
                 dst[(NP - 1) * W::V_PART_U4 * 2] = uint2{ w2s_pack(l[0], l[1]), w2s_pack(l[2], l[3]) };
                 }
             };
-            put(0, r[0] - r[2]);
+            f32x4 c0 = r[0], c2 = r[2], c3 = r[1];
+            w2s_sub4(c0, r[2], neg1);
+            w2s_sub4(c2, r[1], neg1);
+            w2s_sub4(c3, r[3], neg1);
+            put(0, c0);
             put(1, r[1] + r[2]);
-            put(2, r[2] - r[1]);
-            put(3, r[1] - r[3]);
+            put(2, c2);
+            put(3, c3);
         }
     };
 
@@ -215,47 +269,85 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
 #pragma unroll
             for (int t = 0; t < MT; t++) Y[i][j][t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 
+    // output transform of one tile step: Y[i][j][t] += At[i][p] * At[j][q] * m,  At = (1 1 1 0 ; 0 1 -1 -1), as PLAIN adds /
+    // subtracts in the shadow of the next tile step's MFMAs (round 3, tools/ubench/mfma_f16_valu3.hip: a plain vector
+    // instruction issues beside another wave's -- and, two per MFMA, its own wave's -- MFMAs for free; a packed fp32 one
+    // never does, and the optimiser packs every vector addition it sees: hence the asm).  The `groups` calls after a tile
+    // step's MFMAs each take every groups-th of the up to 16 additions.
+    f32x4 mr[3];
+    auto out_tf = [&](int p, int q, int t, const f32x4& m, int groups, int g) {
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int ci = (i == 0) ? (p < 3 ? 1 : 0) : (p == 0 ? 0 : (p == 1 ? 1 : -1));
+                const int cj = (j == 0) ? (q < 3 ? 1 : 0) : (q == 0 ? 0 : (q == 1 ? 1 : -1));
+                if (ci * cj == 0) continue;
+#pragma unroll
+                for (int e = 0; e < 4; e++, n++) {
+                    if (n % groups != g) continue;
+                    if (ci * cj > 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(Y[i][j][t][e]) : "v"(m[e]));
+                    else asm volatile("v_sub_f32 %0, %0, %1" : "+v"(Y[i][j][t][e]) : "v"(m[e]));
+                }
+            }
+    };
+
     load_img(0);
     load_b(0, wf[0]);
     __syncthreads();                                 // the zero fills and the table are complete
     store_img();
+    W2S_STAMP(1);
 
 #pragma unroll 1
     for (int chunk = 0; chunk < 4; chunk++) {
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             __syncthreads();                         // the image is staged; every wave has read the previous row of V
-            if (p == 2 && chunk + 1 < 4) load_img(chunk + 1);      // in flight during this row
+            if (p == 2 && chunk + 1 < 4 && !(W2S_DIAG & 8)) load_img(chunk + 1);      // in flight during this row
             transform(p);
             __syncthreads();                         // V complete; (p == 3) the image is dead
-            if (p == 3 && chunk + 1 < 4) store_img();
+            W2S_STAMP(2 + 2 * (4 * chunk + p));
+            if (p == 3 && chunk + 1 < 4 && !(W2S_DIAG & 8)) store_img();
             uint4 vf[2][NP];                          // (plain words: a bf16 vector across a branch is re-packed element-wise)
             v_read(0, 0, vf[0]);
-#pragma unroll 1
-            for (int q2 = 0; q2 < 2; q2++) {
-                // two stages per trip: the weight sets and the fragment ring (14 tile steps) come out even
+            // the row's four stages unrolled (round 3): the output transform's factors are compile-time signs, so it is
+            // packed adds / subtracts of the products that count only (63 per stage on average; with q a run-time value
+            // it was 84 multiply-adds, a third of them by 0.0)
 #pragma unroll
-                for (int qq = 0; qq < 2; qq++) {
-                    const int q = 2 * q2 + qq;
+            for (int q = 0; q < 4; q++) {
+                {
+                    const int qq = q & 1;
                     const int s = chunk * 16 + p * 4 + q;
-                    load_b(s + 1 < 64 ? s + 1 : 63, wf[(qq + 1) & 1]);   // unconditional: the wait counts stay exact
-                    f32x4 m[MT];
+                    if (!(W2S_DIAG & 16)) load_b(s + 1 < 64 ? s + 1 : 63, wf[(qq + 1) & 1]);   // unconditional: the wait counts stay exact
 #pragma unroll
                     for (int t = 0; t < MT; t++) {
-                        const int n = qq * MT + t;   // tile step of the trip; its fragments sit in vf[n & 1]
+                        const int n = q * MT + t;    // tile step of the row; its fragments sit in vf[n & 1], its products go to mr[n % 3]
                         if (t + 1 < MT) v_read(q, t + 1, vf[(n + 1) & 1]);
                         else v_read(q < 3 ? q + 1 : 3, 0, vf[(n + 1) & 1]);          // (q == 3: a harmless re-read)
+                        // the products of tile step n - 2 (stage (p, qp), tile tp) are added to Y behind this one's MFMAs: nothing
+                        // tells the compiler that the asm reads an MFMA's result, so the distance (>= 3 MFMAs = 48 cycles) is
+                        // what keeps the read behind the matrix pipe's write
+                        const int qp = (n - 2) / MT, tp = (n - 2) % MT;
                         f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
                         if constexpr (NP == 1) {
-                            m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[qq][0]),
-                                                                          __builtin_bit_cast(f16x8, vf[n & 1][0]), acc, 0, 0, 0);
+                            mr[n % 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[qq][0]),
+                                                                               __builtin_bit_cast(f16x8, vf[n & 1][0]), acc, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (n > 1) out_tf(p, qp, tp, mr[(n + 1) % 3], 1, 0);
                         } else if constexpr (NP == 2) {
                             const f16x8 u0 = __builtin_bit_cast(f16x8, wf[qq][0]), u1 = __builtin_bit_cast(f16x8, wf[qq][1]);
                             const f16x8 v0 = __builtin_bit_cast(f16x8, vf[n & 1][0]), v1 = __builtin_bit_cast(f16x8, vf[n & 1][1]);
                             // the three products of weight up to 2^-11, smallest first
                             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(u1, v0, acc, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (n > 1) out_tf(p, qp, tp, mr[(n + 1) % 3], 3, 0);
                             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(u0, v1, acc, 0, 0, 0);
-                            m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u0, v0, acc, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (n > 1) out_tf(p, qp, tp, mr[(n + 1) % 3], 3, 1);
+                            mr[n % 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u0, v0, acc, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (n > 1) out_tf(p, qp, tp, mr[(n + 1) % 3], 3, 2);
                         } else {
                             const bf16x8 u0 = __builtin_bit_cast(bf16x8, wf[qq][0]), u1 = __builtin_bit_cast(bf16x8, wf[qq][1]),
                                          u2 = __builtin_bit_cast(bf16x8, wf[qq][NP - 1]);
@@ -264,111 +356,144 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
                             // the six products of weight up to 2^-16, smallest first
                             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u2, v[0], acc, 0, 0, 0);
                             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[2], acc, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (n > 1) out_tf(p, qp, tp, mr[(n + 1) % 3], 3, 0);
                             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, v[1], acc, 0, 0, 0);
                             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, v[0], acc, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (n > 1) out_tf(p, qp, tp, mr[(n + 1) % 3], 3, 1);
                             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[1], acc, 0, 0, 0);
-                            m[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[0], acc, 0, 0, 0);
+                            mr[n % 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, v[0], acc, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (n > 1) out_tf(p, qp, tp, mr[(n + 1) % 3], 3, 2);
                         }
                         __builtin_amdgcn_sched_barrier(0);             // keep the pipeline as written
                     }
-                    // output transform: Y[i][j] += At[i][p] * At[j][q] * M,  At = (1 1 1 0 ; 0 1 -1 -1); p is unrolled
-                    // (compile-time row factor), q is a run-time value (column factor as +-1.0 / 0)
-                    const float cj0 = (q < 3) ? 1.0f : 0.0f;
-                    const float cj1 = (q == 0) ? 0.0f : (q == 1 ? 1.0f : -1.0f);
-#pragma unroll
-                    for (int i = 0; i < 2; i++) {
-                        const int ci = (i == 0) ? (p < 3 ? 1 : 0) : (p == 0 ? 0 : (p == 1 ? 1 : -1));
-                        if (ci != 0) {
-                            const float f0 = ci > 0 ? cj0 : -cj0, f1 = ci > 0 ? cj1 : -cj1;
-#pragma unroll
-                            for (int t = 0; t < MT; t++)
-#pragma unroll
-                                for (int e = 0; e < 4; e++) {
-                                    Y[i][0][t][e] = fmaf(f0, m[t][e], Y[i][0][t][e]);
-                                    Y[i][1][t][e] = fmaf(f1, m[t][e], Y[i][1][t][e]);
-                                }
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            // the row's last two tile steps (numbers 4 * MT - 2 and 4 * MT - 1), the last one at a safe distance from its MFMAs
+            out_tf(p, 3, MT - 2, mr[(4 * MT - 2) % 3], 1, 0);
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15");
+            out_tf(p, 3, MT - 1, mr[(4 * MT - 1) % 3], 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            W2S_STAMP(3 + 2 * (4 * chunk + p));
         }
     }
 
     // epilogue.  The products are formed transposed (A operand = weights, B operand = V), so in the C/D layout of
     // a 16x16 tile (col = lane & 15, row = 4 * (lane >> 4) + reg) a lane holds FOUR CONSECUTIVE output channels
-    // of ONE wtile: one 16-byte load / store per output cell.
-    // The residual of a whole group of tiles is requested before the first store (off-board cells read the lane's
-    // first cell instead: no branch around a load), so the loads' latency is paid once per group, not once per cell.
-    const int col = wave * 16 + 4 * lq;
+    // of ONE wtile -- but NEIGHBOURING LANES hold different wtiles, cells 512 bytes apart in memory: stored from there,
+    // every 16-byte piece is a cache-line access of its own, and the texture path's one line per clock, not HBM, sets
+    // the epilogue's length (12-13 us of a workgroup's 67 at 13x13).  Round 3: each tile's cells go through a
+    // wave-private kilobyte of LDS and come back with four consecutive lanes on the 64 bytes a wave owns of one
+    // cell (lane L: wtile 16 t + L / 4, channels 4 (L & 3) ..): residual loads and stores are then 64-byte runs.
+    // Residual and output are buffer accesses relative to the workgroup's first board: 32-bit offsets, and a cell off
+    // the board (or a tile / board that does not exist) gets an offset beyond the descriptor's range -- its load
+    // returns zeros and its store is dropped, without a branch.
+    const int eq = lane & 3, ew = lane >> 2;                 // the lane's channel quad and wtile (of 16) after the exchange
+    const int col = wave * 16 + 4 * eq;
     const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col]);
     f32x4 hwv[3];
-    float* hp = reinterpret_cast<float*>(lds) + (size_t)((wave * 4 + lq) * (W::NBW * P)) * 3;
+    float* hp = reinterpret_cast<float*>(lds) + (size_t)((wave * 4 + eq) * (W::NBW * P)) * 3;
     if constexpr (HEADS) {
 #pragma unroll
         for (int c = 0; c < 3; c++) hwv[c] = *reinterpret_cast<const f32x4*>(&head_w[c * 128 + col]);
-        __syncthreads();                                     // every wave has read the last row of V: LDS is free
     }
-    constexpr int GT = 4;                                    // tiles per group: 16 loads in flight
+    __syncthreads();                                         // every wave has read the last row of V: LDS is free
+    W2S_STAMP(37);
+    f32x4* xch = HEADS ? lds + W::HP_U4 + wave * W::XCH_HEADS_WAVE_U4 : lds + wave * W::XCH_WAVE_U4;
+    // tile t's four cells from lane (li, lq) = (wtile, quad) into the exchange area (17: no bank conflicts on either side)
+    auto xch_put = [&](int t) {
 #pragma unroll
-    for (int t0 = 0; t0 < MT; t0 += GT) {
-        long off[GT][4];
-        bool ok[GT][4];
-        f32x4 rv[GT][4];
-        int brd[GT];                                         // board of the tile within the workgroup (NP == 2)
+        for (int ij = 0; ij < 4; ij++) xch[((t & 1) * 4 + ij) * 72 + lq * 17 + li] = Y[ij >> 1][ij & 1][t];
+        asm volatile("" ::: "memory");
+    };
+    const int nb_here = nboards - b_first < W::NBW ? nboards - b_first : W::NBW;
+    const auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RESID ? resid : bias) + (RESID && !(W2S_DIAG & 64) ? (size_t)b_first * P * 128 : 0), 0,
+                                                         RESID ? nb_here * P * 512 : 0, 0x00020000);
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out + (HEADS || (W2S_DIAG & 64) ? 0 : (size_t)b_first * P * 128), 0, HEADS ? 0 : nb_here * P * 512, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    int cur_b = -1;                                          // NP <= 2: the board this lane's tiles have been on, and the
+    float cur_m = 0.0f;                                      // largest value it stored for it
+    auto flush_bound = [&]() {
+        if (cur_b >= 0 && __float_as_uint(cur_m) > amax_out[cur_b]) atomicMax(&amax_out[cur_b], __float_as_uint(cur_m));
+    };
+    // offsets, board and residual of tile t in the lane's new place
+    auto tile_at = [&](int t, unsigned* vo, int& brd, f32x4* rv) {
+        const int w = t * 16 + ew;
+        const int bl = w / W::T2, rem = w - bl * W::T2;
+        const bool tile_ok = w < W::WT && bl < nb_here;
+        brd = tile_ok ? bl : -1;
+        const int ty = rem / W::T, tx = rem - ty * W::T;
+        const unsigned tb = (unsigned)(((bl * P + 2 * ty * S + 2 * tx) * 128 + col) * 4);
 #pragma unroll
-        for (int g = 0; g < GT; g++) {
-            const int t = t0 + g;
-            const int w = t * 16 + li;
-            const int bl = w / W::T2, rem = w - bl * W::T2;
-            const long board = b_first + bl;
-            const bool tile_ok = t < MT && w < W::WT && board < nboards;
-            brd[g] = tile_ok ? bl : -1;
-            const int ty = rem / W::T, tx = rem - ty * W::T;
-#pragma unroll
-            for (int ij = 0; ij < 4; ij++) {
-                const int y = 2 * ty + (ij >> 1), x = 2 * tx + (ij & 1);
-                ok[g][ij] = tile_ok && y < S && x < S;
-                off[g][ij] = ok[g][ij] ? (board * P + y * S + x) * 128 + col : (long)b_first * P * 128 + col;
-                if (RESID) rv[g][ij] = *reinterpret_cast<const f32x4*>(&resid[off[g][ij]]);
-            }
+        for (int ij = 0; ij < 4; ij++) {
+            const bool ok = tile_ok && 2 * ty + (ij >> 1) < S && 2 * tx + (ij & 1) < S;
+            vo[ij] = ok ? tb + (unsigned)(((ij >> 1) * S + (ij & 1)) * 512) : OOB;
+            if (RESID && !(W2S_DIAG & 4)) rv[ij] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, vo[ij], 0, 0));
+            else rv[ij] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
         }
+    };
+    unsigned vo[2][4];
+    int brd[2];
+    f32x4 rv[2][4];
+    tile_at(0, vo[0], brd[0], rv[0]);
+    if constexpr (!HEADS) xch_put(0);
 #pragma unroll
-        for (int g = 0; g < GT; g++) {
-            if (t0 + g >= MT) continue;
-            // NP == 2: the accumulators are scaled back by 2^-(input scale of the tile's board + weight scale)
-            const int back = NP <= 2 ? -(f16_scale_exp(amax_in[brd[g] < 0 ? 0 : brd[g]], 4) + wexp) : 0;
-            float mx = 0.0f;
+    for (int t = 0; t < MT; t++) {
+        if (t + 1 < MT) {                                    // the next tile's residual and its cells are on their way
+            tile_at(t + 1, vo[(t + 1) & 1], brd[(t + 1) & 1], rv[(t + 1) & 1]);
+            if constexpr (!HEADS) xch_put(t + 1);
+        }
+        const int tb = t & 1;
+        // NP <= 2: the accumulators are scaled back by 2^-(input scale of the tile's board + weight scale)
+        const int back = NP <= 2 ? -(f16_scale_exp(amax_in[brd[tb] < 0 ? 0 : brd[tb]], 4) + wexp) : 0;
+        float mx = 0.0f;
 #pragma unroll
-            for (int ij = 0; ij < 4; ij++) {
-                f32x4 v = Y[ij >> 1][ij & 1][t0 + g];
-                if constexpr (NP <= 2) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = __builtin_ldexpf(v[e], back);
-                }
-                v += bv;
-                if (RESID) v += rv[g][ij];
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
-                if (ok[g][ij]) {
-                    if constexpr (HEADS) {
-                        const int lcell = (int)(off[g][ij] >> 7) - b_first * P;      // (off = cell * 128 + col, col < 128)
-#pragma unroll
-                        for (int c = 0; c < 3; c++)
-                            hp[lcell * 3 + c] = fmaf(v[3], hwv[c][3], fmaf(v[2], hwv[c][2], fmaf(v[1], hwv[c][1], v[0] * hwv[c][0])));
-                    } else
-                        *reinterpret_cast<f32x4*>(&out[off[g][ij]]) = v;
-                    if constexpr (NP <= 2) mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
-                }
-            }
+        for (int ij = 0; ij < 4; ij++) {
+            f32x4 v;                                                         // the cell as lane L sees it: wtile L / 4, quad L & 3
+            if constexpr (HEADS) {
+                xch[(ij & 1) * 72 + lq * 17 + li] = Y[ij >> 1][ij & 1][t];
+                asm volatile("" ::: "memory");
+                v = xch[(ij & 1) * 72 + eq * 17 + ew];
+                asm volatile("" ::: "memory");
+            } else
+                v = xch[((t & 1) * 4 + ij) * 72 + eq * 17 + ew];
             if constexpr (NP <= 2) {
-                // the largest value stored for the tile's board: over the four lanes (lq) that hold the tile, then into LDS
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                if (lq == 0 && brd[g] >= 0 && __float_as_uint(mx) > amax_out[brd[g]]) atomicMax(&amax_out[brd[g]], __float_as_uint(mx));
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = __builtin_ldexpf(v[e], back);
+            }
+            v += bv;
+            if (RESID) v += rv[tb][ij];
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
+            if constexpr (HEADS) {
+                if (vo[tb][ij] != OOB) {
+                    const int lcell = (int)(vo[tb][ij] >> 9);                            // (offset = (cell * 128 + col) * 4, col < 128)
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+                        hp[lcell * 3 + c] = fmaf(v[3], hwv[c][3], fmaf(v[2], hwv[c][2], fmaf(v[1], hwv[c][1], v[0] * hwv[c][0])));
+                }
+            } else if (!(W2S_DIAG & 32))
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w2s_v4u, v), orsrc, vo[tb][ij], 0, 0);
+            if constexpr (NP <= 2) {
+                const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                mx = fmaxf(mx, vo[tb][ij] != OOB ? m4 : 0.0f);
             }
         }
+        asm volatile("" ::: "memory");
+        if constexpr (NP <= 2) {
+            // the largest value stored for the tile's board; into LDS when the lane's tiles move on to the next board
+            if (brd[tb] != cur_b) {
+                flush_bound();
+                cur_b = brd[tb];
+                cur_m = 0.0f;
+            }
+            cur_m = fmaxf(cur_m, mx);
+        }
     }
+    if constexpr (NP <= 2) flush_bound();
+    W2S_STAMP(38);
     if constexpr (NP <= 2 && !HEADS) {
         __syncthreads();
         if (tid < W::NBW && b_first + tid < nboards) amax_io[b_first + tid] = __uint_as_float(amax_out[tid]);
@@ -385,6 +510,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
                 out[((size_t)(b_first + board) * 3 + c) * P + (cell - board * P)] = fmaxf(sum + head_b[c], 0.0f);
         }
     }
+    W2S_STAMP(34);
 }
 
 template <int S, int NP>
