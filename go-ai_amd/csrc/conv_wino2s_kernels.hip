@@ -23,6 +23,7 @@
 // two -- conv_wino3s_kernels.hip explains it; here |Bt d B| <= 4 amax and a launch is one convolution, so the boards'
 // bounds travel between launches in amax_io[board] (read at the start, overwritten with the output's at the end, by
 // the one workgroup that owns the board).
+#include <type_traits>
 #include "go_board.h"
 #include "goai_internal.h"
 #include "nn.h"
@@ -78,7 +79,7 @@ extern "C" int goai_debug_wino2s_stamps(unsigned long long* host_out, int n)
 {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino2s_stamps), (size_t)n * sizeof(unsigned long long));
 }
-#define W2S_STAMP(i) if (RESID && !HEADS && threadIdx.x == 0 && blockIdx.x < 8192) { g_wino2s_stamps[blockIdx.x * 40 + (i)] = __builtin_amdgcn_s_memrealtime(); if ((i) == 0 || (i) == 34) g_wino2s_stamps[blockIdx.x * 40 + 35 + ((i) == 34)] = __builtin_amdgcn_s_memtime(); }
+#define W2S_STAMP(i) if (k == (n_convs > 1) && threadIdx.x == 0 && blockIdx.x < 8192) { g_wino2s_stamps[blockIdx.x * 40 + (i)] = __builtin_amdgcn_s_memrealtime(); if ((i) == 0 || (i) == 34) g_wino2s_stamps[blockIdx.x * 40 + 35 + ((i) == 34)] = __builtin_amdgcn_s_memtime(); }
 #else
 #define W2S_STAMP(i)
 #endif
@@ -100,16 +101,22 @@ __device__ __forceinline__ void w2s_sub4(f32x4& y, const f32x4 m, const f32x2 n1
 // two fp32 bit patterns whose low halves are dropped -> one word of two bf16 (a in the low half)
 __device__ __forceinline__ unsigned w2s_pack(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
-// NP == 2 only: wexp = the weights' scale exponent; amax_first > 0: bound of every board's input, else amax_io[board];
-// amax_io receives the bound of the output, per board.
-// HEADS (the trunk's last convolution): instead of the output, out[board][3][P] = ReLU(the heads' three 1x1 convolutions
-// head_w[3][128], head_b[3] of it), formed as in conv_wino3s_kernels.hip: the output's 128 channels never go to memory.
-template <int S, bool RESID, int NP, bool HEADS>
-__global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict__ in, const uint4* wt,
-                                                        const float* __restrict__ bias,
-                                                        const float* __restrict__ resid, float* __restrict__ out,
-                                                        int nboards, int wexp, float* amax_io, float amax_first,
-                                                        const float* __restrict__ head_w, const float* __restrict__ head_b)
+// One launch runs n_convs convolutions in a row on the same boards (a workgroup owns whole boards; round 3: the whole
+// residual trunk, as conv_wino3h_kernels.hip does on 9x9): convolution 0 is y = relu(conv(x) + bias (+ resid0)), then
+// x = relu(conv(y) + bias + x), y = relu(conv(x) + bias), ... : what a workgroup wrote it reads back itself (L2), the
+// boards' bounds stay in LDS, the zero borders are filled once per convolution.  wt_all / bias_all / wexp_all: the
+// convolutions' weight images, biases and (NP <= 2) weight scale exponents, consecutive.
+// NP <= 2: amax_first > 0: bound of every board's input, else amax_io[board]; amax_io (may be NULL) receives the bounds
+// of the last output, per board.
+// head_out != NULL (the last convolution must have a residual): instead of the last output, head_out[board][3][P] =
+// ReLU(the heads' three 1x1 convolutions head_w[3][128], head_b[3] of it), formed as in conv_wino3s_kernels.hip: the
+// output's 128 channels never go to memory.
+template <int S, int NP>
+__global__ __launch_bounds__(512) void k_conv3x3_wino2s(float* x, float* y, const float* resid0, const uint4* wt_all,
+                                                        const float* __restrict__ bias_all, int nboards, int n_convs,
+                                                        const int* __restrict__ wexp_all, float* amax_io, float amax_first,
+                                                        const float* __restrict__ head_w, const float* __restrict__ head_b,
+                                                        float* head_out)
 {
     using W = Wino2S<S, NP>;
     constexpr int P = W::P, MT = W::MT;
@@ -128,24 +135,26 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     if (blockIdx.x < 256)
         for (int i = 0; i < (int)(blockIdx.x % W2S_STAGGER) * (20 / (W2S_STAGGER - 1) + 1); i++) __builtin_amdgcn_s_sleep(127);
 #endif
-    W2S_STAMP(0);
 
-    // V rows WT..ROWS-1 are never written: they stay zero and only reach accumulator columns that are never stored
-    // (and the image region: its border cells are never written)
-    for (int i = tid; i < W::IMG_U4 + W::V_U4; i += 512) lds[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    const float* in = x;                              // of the current convolution (not __restrict__: the workgroup reads
+    float* out = y;                                   // back what it wrote)
+    const float* resid = resid0;
     if (NP <= 2 && tid < 16) {
         const bool on = tid < W::NBW && b_first + tid < nboards;
-        amax_in[tid] = __float_as_uint(!on ? 0.0f : amax_first > 0.0f ? amax_first : amax_io[b_first + tid]);
-        amax_out[tid] = 0u;
+        amax_out[tid] = __float_as_uint(!on ? 0.0f : amax_first > 0.0f ? amax_first : amax_io[b_first + tid]);
     }
     f32x2 neg1 = { -1.0f, -1.0f };                    // (w2s_sub4)
     asm volatile("" : "+v"(neg1));
     const int ts = tid & 7;                           // 4-channel slot of this thread's input-transform items
+    // the thread's number as the image staging and the epilogue see it: renewed (opaquely) at every convolution, or the
+    // optimiser computes their ~60 offsets, which do not depend on the convolution, once in front of the loop over the
+    // convolutions and spills them around the stages
+    int tidv = tid;
     f32x4 ireg[W::NI];
     auto load_img = [&](int chunk) {
 #pragma unroll
         for (int i = 0; i < W::NI; i++) {
-            const int idx = tid + i * 512;
+            const int idx = tidv + i * 512;
             const int cr = idx >> 3, slot = idx & 7;
             const int board = b_first + cr / P;
             f32x4 v = { 0.0f, 0.0f, 0.0f, 0.0f };
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     auto store_img = [&]() {
 #pragma unroll
         for (int i = 0; i < W::NI; i++) {
-            const int idx = tid + i * 512;
+            const int idx = tidv + i * 512;
             if (idx < W::NBW * P * 8) {
                 const int cr = idx >> 3, bl = cr / P, rem = cr - bl * P, yy = rem / S, xx = rem - yy * S;
                 f32x4* dst = &Img[W::slot_at(W::cell(bl, yy, xx), idx & 7)];
@@ -245,7 +254,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     // vector offset = the lane's place in the stage -- no address arithmetic in the loop
     constexpr unsigned W_STAGE_BYTES = 8 * 64 * NP * 16;
     const unsigned wlane = (wave * (64 * NP) + lane) * 16;
-    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wt), 0, 64 * W_STAGE_BYTES, 0x00020000);
+    const uint4* wt = wt_all;
+    auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wt), 0, 64 * W_STAGE_BYTES, 0x00020000);
     u32x4 wf[2][NP];
     auto load_b = [&](int stage, u32x4* b) {
 #pragma unroll
@@ -262,12 +272,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     };
 
     f32x4 Y[2][2][MT];                               // [i][j]: output (2ty + i, 2tx + j) of the wtile
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int t = 0; t < MT; t++) Y[i][j][t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 
     // output transform of one tile step: Y[i][j][t] += At[i][p] * At[j][q] * m,  At = (1 1 1 0 ; 0 1 -1 -1), as PLAIN adds /
     // subtracts in the shadow of the next tile step's MFMAs (round 3, tools/ubench/mfma_f16_valu3.hip: a plain vector
@@ -293,9 +297,31 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
             }
     };
 
+#pragma unroll 1
+    for (int k = 0; k < n_convs; k++) {
+    const float* bias = bias_all + k * 128;
+    const int wexp = NP <= 2 ? wexp_all[k] : 0;
+    // k > 0: every wave is through the previous epilogue (its stores are visible to the workgroup, the exchange area is dead)
+    __syncthreads();
+    tidv = tid;
+    asm volatile("" : "+v"(tidv));
+    W2S_STAMP(0);
     load_img(0);
     load_b(0, wf[0]);
-    __syncthreads();                                 // the zero fills and the table are complete
+    // V rows WT..ROWS-1 and the image's border cells are never written by the loop below: they stay zero (the V rows only
+    // reach accumulator columns that are never stored); the epilogue's exchange area lies over both, hence once per convolution
+    for (int i = tid; i < W::IMG_U4 + W::V_U4; i += 512) lds[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    if (NP <= 2 && tid < 16) {                       // the bounds the previous epilogue (or the prologue) collected
+        amax_in[tid] = amax_out[tid];
+        amax_out[tid] = 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int t = 0; t < MT; t++) Y[i][j][t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    __syncthreads();                                 // the zero fills are complete
     store_img();
     W2S_STAMP(1);
 
@@ -390,7 +416,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     // Residual and output are buffer accesses relative to the workgroup's first board: 32-bit offsets, and a cell off
     // the board (or a tile / board that does not exist) gets an offset beyond the descriptor's range -- its load
     // returns zeros and its store is dropped, without a branch.
-    const int eq = lane & 3, ew = lane >> 2;                 // the lane's channel quad and wtile (of 16) after the exchange
+    auto epilogue = [&](auto has_resid, auto to_heads) {
+    constexpr bool RESID = decltype(has_resid)::value, HEADS = decltype(to_heads)::value;
+    const int lane_e = tidv & 63;
+    const int li = lane_e & 15, lq = lane_e >> 4;            // (shadow the kernel's: see tidv)
+    const int eq = lane_e & 3, ew = lane_e >> 2;             // the lane's channel quad and wtile (of 16) after the exchange
     const int col = wave * 16 + 4 * eq;
     const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[col]);
     f32x4 hwv[3];
@@ -411,7 +441,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     const int nb_here = nboards - b_first < W::NBW ? nboards - b_first : W::NBW;
     const auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RESID ? resid : bias) + (RESID && !(W2S_DIAG & 64) ? (size_t)b_first * P * 128 : 0), 0,
                                                          RESID ? nb_here * P * 512 : 0, 0x00020000);
-    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out + (HEADS || (W2S_DIAG & 64) ? 0 : (size_t)b_first * P * 128), 0, HEADS ? 0 : nb_here * P * 512, 0x00020000);
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out + ((W2S_DIAG & 64) ? 0 : (size_t)b_first * P * 128), 0, HEADS ? 0 : nb_here * P * 512, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     int cur_b = -1;                                          // NP <= 2: the board this lane's tiles have been on, and the
     float cur_m = 0.0f;                                      // largest value it stored for it
@@ -494,10 +524,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
     }
     if constexpr (NP <= 2) flush_bound();
     W2S_STAMP(38);
-    if constexpr (NP <= 2 && !HEADS) {
-        __syncthreads();
-        if (tid < W::NBW && b_first + tid < nboards) amax_io[b_first + tid] = __uint_as_float(amax_out[tid]);
-    }
     if constexpr (HEADS) {
         __syncthreads();
         const float* hs = reinterpret_cast<const float*>(lds);
@@ -507,61 +533,71 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(const float* __restrict_
 #pragma unroll 8
             for (int sl = 0; sl < 32; sl++) sum += hs[(size_t)sl * (W::NBW * P * 3) + o];
             if (b_first + board < nboards)
-                out[((size_t)(b_first + board) * 3 + c) * P + (cell - board * P)] = fmaxf(sum + head_b[c], 0.0f);
+                head_out[((size_t)(b_first + board) * 3 + c) * P + (cell - board * P)] = fmaxf(sum + head_b[c], 0.0f);
         }
     }
+    };
+    const bool heads_now = head_out != nullptr && k == n_convs - 1;
+    if (heads_now) epilogue(std::true_type{}, std::true_type{});
+    else if (resid) epilogue(std::true_type{}, std::false_type{});
+    else epilogue(std::false_type{}, std::false_type{});
+    if (NP <= 2 && amax_io && k == n_convs - 1 && !heads_now) {
+        __syncthreads();
+        if (tid < W::NBW && b_first + tid < nboards) amax_io[b_first + tid] = __uint_as_float(amax_out[tid]);
+    }
     W2S_STAMP(34);
+    // next convolution of the launch: swap the buffers, step the weights
+    if (k & 1) { in = x; out = y; resid = resid0; } else { in = y; out = x; resid = x; }
+    wt += 64 * 8 * 64 * NP;
+    wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wt), 0, 64 * W_STAGE_BYTES, 0x00020000);
+    }
 }
 
 template <int S, int NP>
-static int launch_wino2s_size(const float* in, const void* wt_split, const float* bias, const float* resid, float* out,
-                              int nboards, hipStream_t st, int wexp, float* amax_io, float amax_first, const float* head_w,
-                              const float* head_b)
+static int launch_wino2s_size(float* x, float* y, const float* resid0, const void* wt_split, const float* bias, int nboards, int n_convs,
+                              hipStream_t st, const int* wexp, float* amax_io, float amax_first, const float* head_w,
+                              const float* head_b, float* head_out)
 {
     const int grid = (nboards + Wino2S<S, NP>::NBW - 1) / Wino2S<S, NP>::NBW;
-    const uint4* wt = reinterpret_cast<const uint4*>(wt_split);
-    if (head_w && !resid) {
-        set_error("the heads' 1x1 convolutions are formed by a block's second convolution (with its residual)");
-        return GOAI_ERR_ARG;
-    }
-    if (head_w)
-        k_conv3x3_wino2s<S, true, NP, true><<<dim3(grid), dim3(512), 0, st>>>(in, wt, bias, resid, out, nboards, wexp, amax_io, amax_first,
-                                                                              head_w, head_b);
-    else if (resid)
-        k_conv3x3_wino2s<S, true, NP, false><<<dim3(grid), dim3(512), 0, st>>>(in, wt, bias, resid, out, nboards, wexp, amax_io, amax_first,
-                                                                               nullptr, nullptr);
-    else
-        k_conv3x3_wino2s<S, false, NP, false><<<dim3(grid), dim3(512), 0, st>>>(in, wt, bias, resid, out, nboards, wexp, amax_io, amax_first,
-                                                                                nullptr, nullptr);
+    k_conv3x3_wino2s<S, NP><<<dim3(grid), dim3(512), 0, st>>>(x, y, resid0, reinterpret_cast<const uint4*>(wt_split), bias, nboards, n_convs, wexp,
+                                                              amax_io, amax_first, head_w, head_b, head_out);
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }
 
-// wt_split: [64 stages][8 waves][parts][64 lanes][8 x 16 bit] of one convolution (nn_host.hip).
-// parts = 3: bf16; parts = 2: fp16, which also takes the weights' scale exponent wexp and the boards' bounds
-// amax_io[nboards] (read unless amax_first > 0 bounds every board's input; always written).
-// head_w != NULL: `out` receives [board][3][P] = the heads' 1x1 convolutions of the output (see the kernel) instead of it.
-int launch_conv3x3_wino2s(int S_rt, const float* in, const void* wt_split, const float* bias, const float* resid,
-                          float* out, int nboards, hipStream_t st, int parts, int wexp, float* amax_io, float amax_first,
-                          const float* head_w, const float* head_b)
+// n_convs = 1: y = relu(conv(x) + bias (+ resid0)); n_convs = 2 * blocks, resid0 = NULL: the whole residual trunk in one
+// launch (weights / biases / scale exponents of consecutive convolutions contiguous), result in x.
+// wt_split: [n_convs][64 stages][8 waves][parts][64 lanes][8 x 16 bit] (nn_host.hip).
+// parts = 3: bf16; parts = 2 / 1: fp16, which also takes the weights' scale exponents wexp[n_convs] (device memory) and the
+// boards' bounds: the first input's are amax_first > 0 for every board or amax_io[nboards]; amax_io (may be NULL when
+// amax_first > 0) receives the last output's.
+// head_out != NULL: it receives [board][3][P] = the heads' 1x1 convolutions (head_w, head_b) of the last output (see the
+// kernel) instead of the output going to memory; the last convolution must be one with a residual.
+int launch_conv3x3_wino2s(int S_rt, float* x, float* y, const float* resid0, const void* wt_split, const float* bias, int nboards,
+                          int n_convs, hipStream_t st, int parts, const int* wexp, float* amax_io, float amax_first,
+                          const float* head_w, const float* head_b, float* head_out)
 {
+    if (nboards < 1 || n_convs < 1 || (n_convs > 1 && ((n_convs & 1) || resid0))) {
+        set_error("the F(2x2,3x3) trunk launch runs whole residual blocks (an even number of convolutions, no outer residual) or one convolution");
+        return GOAI_ERR_ARG;
+    }
+    if (head_out && (!head_w || !head_b || (n_convs == 1 && !resid0))) {
+        set_error("the heads' 1x1 convolutions are formed by a block's second convolution (with its residual)");
+        return GOAI_ERR_ARG;
+    }
+    if (parts <= 2 && (!wexp || (!amax_io && !(amax_first > 0.0f)))) {
+        set_error("the fp16 F(2x2,3x3) convolution needs the weights' scale exponents and the boards' bounds");
+        return GOAI_ERR_ARG;
+    }
     if (parts == 1) {
-        if (!amax_io) {
-            set_error("the fp16 F(2x2,3x3) convolution needs the boards' bounds (amax_io)");
-            return GOAI_ERR_ARG;
-        }
-        GOAI_DISPATCH_SIZE(S_rt, return (launch_wino2s_size<S, 1>(in, wt_split, bias, resid, out, nboards, st, wexp, amax_io, amax_first, head_w, head_b)));
+        GOAI_DISPATCH_SIZE(S_rt, return (launch_wino2s_size<S, 1>(x, y, resid0, wt_split, bias, nboards, n_convs, st, wexp, amax_io, amax_first, head_w, head_b, head_out)));
         return GOAI_OK;
     }
     if (parts == 2) {
-        if (!amax_io) {
-            set_error("the fp16 F(2x2,3x3) convolution needs the boards' bounds (amax_io)");
-            return GOAI_ERR_ARG;
-        }
-        GOAI_DISPATCH_SIZE(S_rt, return (launch_wino2s_size<S, 2>(in, wt_split, bias, resid, out, nboards, st, wexp, amax_io, amax_first, head_w, head_b)));
+        GOAI_DISPATCH_SIZE(S_rt, return (launch_wino2s_size<S, 2>(x, y, resid0, wt_split, bias, nboards, n_convs, st, wexp, amax_io, amax_first, head_w, head_b, head_out)));
         return GOAI_OK;
     }
-    GOAI_DISPATCH_SIZE(S_rt, return (launch_wino2s_size<S, 3>(in, wt_split, bias, resid, out, nboards, st, 0, nullptr, 0.0f, head_w, head_b)));
+    GOAI_DISPATCH_SIZE(S_rt, return (launch_wino2s_size<S, 3>(x, y, resid0, wt_split, bias, nboards, n_convs, st, nullptr, nullptr, 0.0f, head_w, head_b, head_out)));
     return GOAI_OK;
 }
 

@@ -31,7 +31,7 @@ struct Net {
     int wino_mode = 0;         // 0: direct kernel, 2: Winograd F(2x2,3x3), 3: Winograd F(3x3,3x3) (chosen in nn_init)
     bool wino3_paired = false; // F(3x3,3x3) with two chunks per output transform (conv_wino3p_kernels.hip): max_batch <= 4 * CUs
     void* wino3p_tab = nullptr;
-    bool trunk_fused = false;  // F(3x3,3x3) only: all 2 * layers convolutions of a forward in one launch
+    bool trunk_fused = false;  // F(3x3,3x3) and the split F(2x2,3x3): all 2 * layers convolutions of a forward in one launch
     float* wt_wino3 = nullptr; // F(3x3,3x3): [2*layers][4 chunks][25 xi][128 out][32 in]
     void* wino3_tab[2] = { nullptr, nullptr };   // input-transform address tables for 4 / 5 boards per workgroup
     int n_cu = 256;
@@ -96,9 +96,11 @@ int launch_conv3x3_wino3s(int S, float* x, float* y, const float* resid0, const 
 int launch_conv3x3_wino3h(int S, float* x, float* y, const float* resid0, const void* wt_split, const float* bias, int nboards,
                           int n_convs, hipStream_t st, int parts, const int* wexp, float* amax_io, float amax_first,
                           const float* head_w = nullptr, const float* head_b = nullptr, float* head_out = nullptr);
-int launch_conv3x3_wino2s(int S, const float* in, const void* wt_split, const float* bias, const float* resid, float* out,
-                          int nboards, hipStream_t st, int parts = 3, int wexp = 0, float* amax_io = nullptr,
-                          float amax_first = 0.0f, const float* head_w = nullptr, const float* head_b = nullptr);
+// the split F(2x2,3x3) convolution of the other board sizes (conv_wino2s_kernels.hip); same launch contract as
+// launch_conv3x3_wino3h: one convolution, or the whole residual trunk (n_convs = 2 * blocks) in one launch
+int launch_conv3x3_wino2s(int S, float* x, float* y, const float* resid0, const void* wt_split, const float* bias, int nboards,
+                          int n_convs, hipStream_t st, int parts, const int* wexp, float* amax_io, float amax_first,
+                          const float* head_w = nullptr, const float* head_b = nullptr, float* head_out = nullptr);
 int launch_conv3x3_wino(int S, const float* in, const float* wt_wino, const float* bias, const float* resid, float* out,
                         int nboards, hipStream_t st);
 // act_is_h: `act` is not the trunk's output [board][P][128] but the heads' 1x1 convolutions of it, [board][3][P]

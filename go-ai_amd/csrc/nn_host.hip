@@ -122,7 +122,8 @@ static int nn_init_impl(goai_ctx* c, int kind, int layers, int max_batch, int dt
         }
         if (n.wino_mode == 2 && !n.split6 && (rc = dev_alloc(c, (void**)&n.wt_wino, (size_t)2 * layers * 16 * 128 * 128 * sizeof(float))))
             return rc;
-        n.trunk_fused = n.wino_mode == 3 && !getenv("GOAI_NO_TRUNK_FUSION");
+        // a workgroup owns whole boards in the F(3x3,3x3) kernels and in the split F(2x2,3x3) kernel: the trunk is one launch
+        n.trunk_fused = (n.wino_mode == 3 || (n.wino_mode == 2 && n.split6)) && !getenv("GOAI_NO_TRUNK_FUSION");
         {
             const char* e = getenv("GOAI_WINO3_PAIRED");
             n.wino3_paired = n.wino_mode == 3 && !n.split6 && wino3p_supported(c->S, max_batch, n.n_cu) && !(e && e[0] == '0');
@@ -464,9 +465,10 @@ static int conv_any(goai_ctx* c, const float* in, int l, const float* b, const f
     const bool wino = net.wino_mode == 2;
     // fp16 parts: the first convolution's input is bounded by amax0, every launch leaves its output's bounds in net.amax
     if (net.split6 && net.wino_mode == 2)
-        return launch_conv3x3_wino2s(c->S, in, (const uint16_t*)net.wt_split6 + (size_t)l * wt_split_per_conv(net), b, resid, out,
-                                     M / c->P, c->stream, net.parts, net.wexp_host[l], net.amax, l == 0 ? net.amax0 : 0.0f,
-                                     heads ? net.hw.conv_w : nullptr, net.hw.conv_b);
+        return launch_conv3x3_wino2s(c->S, const_cast<float*>(in), out, resid,
+                                     (const uint16_t*)net.wt_split6 + (size_t)l * wt_split_per_conv(net), b, M / c->P, 1, c->stream,
+                                     net.parts, net.parts <= 2 ? net.wexp + l : nullptr, net.amax, l == 0 ? net.amax0 : 0.0f,
+                                     heads ? net.hw.conv_w : nullptr, net.hw.conv_b, heads ? out : nullptr);
     if (net.split6 && net.wino3h)
         return launch_conv3x3_wino3h(c->S, const_cast<float*>(in), out, resid,
                                      (const uint16_t*)net.wt_split6 + (size_t)l * wt_split_per_conv(net), b, M / c->P, 1, c->stream,
@@ -523,7 +525,11 @@ static int nn_trunk_on(goai_ctx* c, float* const act[3], int nb, bool prof, floa
             c->prof_events.push_back(e1);
             GOAI_HIP_CHECK(hipEventRecord(e0, c->stream));
         }
-        rc = net.wino3h
+        rc = net.wino_mode == 2
+                 ? launch_conv3x3_wino2s(c->S, x, y, nullptr, net.wt_split6, net.bt, nb, 2 * net.layers, c->stream, net.parts, net.wexp,
+                                         nullptr, net.amax0, net.heads_in_trunk ? net.hw.conv_w : nullptr, net.hw.conv_b,
+                                         net.heads_in_trunk ? net.hbuf : nullptr)
+             : net.wino3h
                  ? launch_conv3x3_wino3h(c->S, x, y, nullptr, net.wt_split6, net.bt, nb, 2 * net.layers, c->stream, net.parts, net.wexp,
                                          nullptr, net.amax0, net.heads_in_trunk ? net.hw.conv_w : nullptr, net.hw.conv_b,
                                          net.heads_in_trunk ? net.hbuf : nullptr)

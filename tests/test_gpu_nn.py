@@ -355,7 +355,7 @@ def test_split_forward_is_fp32_grade(size, kind, n, layers, max_batch, split, mo
         c, sd = make_ctx(kind, size, 100 + size + layers, layers, max_batch, dtype=dtype)
         if name == "split":
             assert c.nn_conv_algo() == (algos[0] if size == 9 else algos[1])
-            assert c.nn_convs_per_launch() == (2 * layers if size == 9 else 1)
+            assert c.nn_convs_per_launch() == 2 * layers
         pi, val = c.nn_forward(states, mode=c.NN_RAW)
         outs[name] = (pi.cpu().numpy() if kind == "ac" else None, val.cpu().numpy())
         if name == "split":
@@ -491,6 +491,36 @@ def test_f16_forward_within_reduced_tolerance(size, kind, n, layers, max_batch, 
     _, val_k = c.nn_forward(states[:k], mode=c.NN_RAW)
     assert np.array_equal(val_k.cpu().numpy(), val.cpu().numpy()[:k])
     c.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16x3", "bf16x6", "f16"])
+def test_f2_split_trunk_in_one_launch_equals_one_launch_per_convolution(dtype, monkeypatch):
+    """Boards other than 9x9 (and 9x9 in the f16 tier) run the split F(2x2,3x3) kernel, conv_wino2s_kernels.hip; since round 3
+    the whole residual trunk is one launch there too (a workgroup owns whole boards, reads back what it wrote, keeps the
+    boards' bounds in LDS).  With GOAI_NO_TRUNK_FUSION=1 the same kernel is launched once per convolution (bounds through
+    Net::amax): the same arithmetic in the same order, heads' 1x1 convolutions included -- bit-identical outputs, ragged last
+    workgroups and 1-board batches included."""
+    from go_ai.engine import Context
+    dt = {"f16x3": Context.DTYPE_F16X3, "bf16x6": Context.DTYPE_BF16X6, "f16": Context.DTYPE_F16}[dtype]
+    cases = [(13, 45, 3, 64), (13, 1, 2, 8), (19, 9, 3, 16), (19, 6, 10, 8), (5, 77, 3, 256), (7, 50, 1, 64)]
+    if dtype == "f16":
+        cases.append((9, 333, 3, 512))
+    for size, n, blocks, mb in cases:
+        states = random_positions(size, n, seed=3 + n, canonical=True, pass_prob=0.05)
+        outs = []
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("GOAI_NO_TRUNK_FUSION", env)
+            else:
+                monkeypatch.delenv("GOAI_NO_TRUNK_FUSION", raising=False)
+            c, sd = make_ctx("ac", size, 40 + blocks, blocks, mb, dtype=dt)
+            assert c.nn_conv_algo() in (Context.CONV_WINOGRAD_F16X3, Context.CONV_WINOGRAD_BF16X6, Context.CONV_WINOGRAD_F16)
+            assert c.nn_convs_per_launch() == (1 if env else 2 * blocks)
+            pi, val = c.nn_forward(states, mode=c.NN_RAW)
+            outs.append((pi.cpu().numpy(), val.cpu().numpy()))
+            c.close()
+        monkeypatch.delenv("GOAI_NO_TRUNK_FUSION", raising=False)
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (size, n, blocks)
 
 
 def test_wino3h_equals_round2_kernel_bit_for_bit(monkeypatch):
