@@ -98,6 +98,12 @@ __device__ __forceinline__ void w2s_sub4(f32x4& y, const f32x4 m, const f32x2 n1
     y = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
+// The 16-byte quarter q (8 channels) of V row r sits at position q ^ w2s_vswz(r) of the row's 64 bytes (round 3, as
+// conv_wino3h_kernels.hip): the 16 lanes that the LDS serves together for a ds_read_b128 ({0-3, 12-15, 20-27}, ...: rows
+// li = 0-3 and 12-15 of one quarter, 4-11 of the next) then touch all 64 banks; unswizzled, every fragment read was a
+// 2-way conflict -- 8 waves x 2 KB per tile step at half rate is more than the 96 cycles of the step's MFMAs.
+__device__ __forceinline__ int w2s_vswz(int row) { return (0 - (row >> 2)) & 3; }
+
 // two fp32 bit patterns whose low halves are dropped -> one word of two bf16 (a in the low half)
 __device__ __forceinline__ unsigned w2s_pack(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(float* x, float* y, cons
                 else if (s1 > 0.0f) { r[b] = img_at(tbase[j], a1, b); w2s_sub4(r[b], img_at(tbase[j], a2, b), neg1); }
                 else { r[b] = img_at(tbase[j], a2, b); w2s_sub4(r[b], img_at(tbase[j], a1, b), neg1); }
             }
-            uint2* V = reinterpret_cast<uint2*>(Vs) + tw * 8 + ts;
+            uint2* V = reinterpret_cast<uint2*>(Vs) + tw * 8 + (((ts >> 1) ^ w2s_vswz(tw)) << 1) + (ts & 1);
             auto put = [&](int q, const f32x4 v) {
                 if constexpr (NP == 1) {
                     V[q * (W::V_PART_U4 * 2)] = __builtin_bit_cast(uint2, __builtin_convertvector(v, f16x4));     // GOAI_DTYPE_F16: one part
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(float* x, float* y, cons
         asm volatile("" ::: "memory");
     };
     auto v_read = [&](int q, int t, uint4* v) {
-        const uint4* V = reinterpret_cast<const uint4*>(Vs) + (q * NP) * W::V_PART_U4 + (t * 16 + li) * 4 + lq;
+        const uint4* V = reinterpret_cast<const uint4*>(Vs) + (q * NP) * W::V_PART_U4 + (t * 16 + li) * 4 + (lq ^ w2s_vswz(li));
 #pragma unroll
         for (int r = 0; r < NP; r++) v[r] = V[r * W::V_PART_U4];
     };
@@ -280,6 +286,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(float* x, float* y, cons
     // step's MFMAs each take every groups-th of the up to 16 additions.
     f32x4 mr[3];
     auto out_tf = [&](int p, int q, int t, const f32x4& m, int groups, int g) {
+        if (W2S_DIAG & 1) {
+            if (g == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(Y[0][0][t][0]) : "v"(m[0]));
+            return;
+        }
         int n = 0;
 #pragma unroll
         for (int i = 0; i < 2; i++)

@@ -234,7 +234,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3h(float* x, float* y, cons
     constexpr unsigned W_STAGE_BYTES = 8 * 64 * NP * 16, W_CONV_BYTES = 100 * W_STAGE_BYTES;
     auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wconv), 0, W_CONV_BYTES, 0x00020000);
     u32x4 wf[2][NP];                                       // two half-stages of weights, used alternately
+#ifndef W3H_DIAG
+#define W3H_DIAG 0      // diagnostic builds only (wrong results): 1 no output transform, 2 every weight load reads stage 0 (L2-hot, same
+#endif                  // instructions), 4 no weight loads after the first, 8 no epilogue stores / residual loads
     auto load_b = [&](int stage, u32x4* b) {
+        if ((W3H_DIAG & 4) && stage > 0) return;
+        if (W3H_DIAG & 2) stage = 0;
 #pragma unroll
         for (int r = 0; r < NP; r++)
             b[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024 * r, stage * W_STAGE_BYTES, 0));
@@ -309,58 +314,60 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3h(float* x, float* y, cons
             for (int t = 0; t < MT; t++) vq[t] = vaddr[t];
 #pragma unroll
             for (int a = 0; a < AH; a++) v_read_step(a, vf[a]);
-            // the row half of row p + 1's transform (main item), one patch column per stage, in the gaps behind this row's
-            // MFMAs: gap 0 of stage q reads column q's cells, gaps G0 .. G0 + 3 form r[q][0..3]
-#ifndef W3H_PIPE
-#define W3H_PIPE 0
-#endif
-            const bool pipe = W3H_PIPE && p < 4;
-            constexpr int G0 = NP == 2 ? 8 : 2;
-            f32x4 dcol[5], rcur;
-            auto gap = [&](const int q, const int g, const int JMv) {
-                if (!pipe) return;
-                if (g == 0) {
-                    const unsigned img_q = it_main.img + q * 128;
-#pragma unroll
-                    for (int a = 0; a < 5; a++)
-                        if ((rows_of(p + 1) >> a) & 1) dcol[a] = patch(img_q, a, 0);
-                } else if (g >= G0 && g < G0 + 4) {
-                    // row_elem(p + 1, dcol, e) as instructions that stay where they are written (plain arithmetic floats to
-                    // its use behind the stage's last MFMA when the instruction selector orders the block)
-                    const int e = g - G0;
-                    float r;
-                    if (p + 1 == 1) {
-                        asm volatile("v_sub_f32 %0, %1, %2\n\tv_fmac_f32 %0, -2.0, %3" : "=&v"(r) : "v"(dcol[3][e]), "v"(dcol[2][e]), "v"(dcol[1][e]));
-                    } else if (p + 1 == 2) {
-                        asm volatile("v_fma_f32 %0, 2.0, %1, %2\n\tv_fmac_f32 %0, 0xc0400000, %3" : "=&v"(r) : "v"(dcol[1][e]), "v"(dcol[3][e]), "v"(dcol[2][e]));
-                    } else if (p + 1 == 3) {
-                        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(dcol[3][e]), "v"(dcol[1][e]));
-                    } else {
-                        asm volatile("v_sub_f32 %0, %1, %2\n\tv_fmac_f32 %0, 2.0, %3\n\tv_fmac_f32 %0, -2.0, %4"
-                                     : "=&v"(r) : "v"(dcol[4][e]), "v"(dcol[2][e]), "v"(dcol[1][e]), "v"(dcol[3][e]));
-                    }
-                    rcur[e] = r;
-                } else if (JMv == 7 && g >= G0 + 4 && g < G0 + 4 + 6) {
-                    // rm[q] = rcur for the run-time q of the middle stages' loop: selects, two per gap
-                    const int s0 = 2 * (g - G0 - 4);
-#pragma unroll
-                    for (int s1 = s0; s1 < s0 + 2; s1++) {
-                        const int b = 1 + s1 / 4, e = s1 % 4;
-                        unsigned long long mask;         // (formed by scalar instructions: as C++ it ended up in vector registers)
-                        asm volatile("s_cmp_eq_u32 %1, %2\n\ts_cselect_b64 %0, -1, 0" : "=s"(mask) : "s"(__builtin_amdgcn_readfirstlane(q)), "n"(b) : "scc");
-                        asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(rm[b][e]) : "v"(rcur[e]), "s"(mask));
-                    }
-                }
+            // Output transform (round 3, second form): Y[i][j] += At[i][p] * At[j][q] * M of stage q - 1 as PLAIN vector
+            // instructions in the shadow of stage q's MFMAs (tools/ubench/mfma_f16_valu3.hip: two plain instructions per MFMA
+            // issue for free, beside the wave's own MFMAs and beside the other wave's; a packed fp32 instruction never
+            // overlaps an MFMA, and behind the MFMAs -- the round-2 form -- the transform cost as much as the products).
+            // Every factor is a compile-time constant (the row's five stages are unrolled; zero factors drop out), the
+            // instructions are asm so that they stay in their gaps and stay unpacked; fma(f, m, y) rounds as before:
+            // bit-identical results.  The products of two stages are alive at a time (mb).
+            auto ci_of = [](int pp, int i) { return i == 0 ? (pp < 4 ? 1 : 0) : i == 1 ? (pp == 1 ? 1 : (pp == 2 ? -1 : (pp == 3 ? 2 : 0))) : (pp == 0 ? 0 : (pp == 3 ? 4 : 1)); };
+            auto is_corner = [](int pp, int qq) { return (pp == 0 || pp == 4) && (qq == 0 || qq == 4); };
+            // the k-th of the rows (columns) i of At with At[i][pp] != 0, and how many there are
+            auto nz_at = [](int pp, int k) { return pp == 0 ? 0 : (pp == 4 ? 2 : k); };
+            auto nnz_of = [](int pp) { return (pp == 0 || pp == 4) ? 1 : 3; };
+            auto n_ops = [&](int pp, int qq) { return (qq < 0 || is_corner(pp, qq)) ? 0 : nnz_of(pp) * nnz_of(qq) * MT * 4; };
+            // operation number n (tile-major) of stage (p, qq)'s transform; jonly >= 0: only if it goes into output column
+            // jonly, jskip >= 0: unless it goes into column jskip
+            // (decoded from n, one instruction form for every factor with the factor in a scalar register: a scan of all
+            // operations per gap, or a choice of instruction by factor, multiplies the code in front of the unroller,
+            // which then gives up -- and Y lands in scratch memory)
+            auto tf_op = [&](const int qq, f32x4 (&m)[MT], const int n, const int jonly, const int jskip) {
+                if ((W3H_DIAG & 1) && (n & 7)) return;
+                const int nj = nnz_of(qq), per_tile = nnz_of(p) * nj * 4;
+                const int t = n / per_tile, r = n % per_tile, pair = r >> 2, e = r & 3;
+                const int i = nz_at(p, pair / nj), j = nz_at(qq, pair % nj);
+                if ((jonly >= 0 && j != jonly) || j == jskip) return;
+                const float f = (float)(ci_of(p, i) * ci_of(qq, j));
+                asm volatile("v_fmac_f32 %0, %2, %1" : "+v"(Y[i][j][t][e]) : "v"(m[t][e]), "s"(f));
             };
-            // one stage (q = the column of the row's five); JM = which output columns j its factors At[j][q] reach
-            // (q = 1..3 run as a loop: fully unrolled, hipcc spills hundreds of registers)
-            auto stage = [&](const int q, auto jmask) {
-                constexpr int JM = decltype(jmask)::value;
-                const bool corner = (JM == 1 || JM == 4) && (p == 0 || p == 4);
-                const int ci_c = (p == 0) ? 0 : 2, cj_c = (JM == 1) ? 0 : 2;
-                f32x4 m[MT];
+            f32x4 mb[2][MT];
+            // one stage (q = the column of the row's five); qpend: the stage whose transform runs in this one's gaps (-1: none)
+            auto stage = [&](const int q, const int qpend) {
+                const bool corner = is_corner(p, q);
+                const int ci_c = (p == 0) ? 0 : 2, cj_c = (q == 0) ? 0 : 2;
+                f32x4 (&m)[MT] = mb[q & 1];
+                f32x4 (&mp)[MT] = mb[(q + 1) & 1];
+                constexpr int NG = 2 * MT * (NP == 2 ? 3 : 1);               // MFMAs = gaps of a stage
+                const int np = n_ops(p, qpend), per_gap = (np + NG - 1) / NG;
+                // a corner stage accumulates in Y itself: what the pending transform adds to that column goes first
+                const int jskip = (corner && np > 0) ? cj_c : -1;
+                if (jskip >= 0) {
+#pragma unroll
+                    for (int n = 0; n < np; n++) tf_op(qpend, mp, n, jskip, -1);
+                    asm volatile("s_nop 7");
+                }
 #pragma unroll
                 for (int t = 0; t < MT; t++) m[t] = corner ? Y[ci_c][cj_c][t] : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+                int gapn = 0;
+                auto gap = [&]() {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < per_gap; k++)
+                        if (gapn * per_gap + k < np) tf_op(qpend, mp, gapn * per_gap + k, -1, jskip);
+                    gapn++;
+                    __builtin_amdgcn_sched_barrier(0);
+                };
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
                     const int h = c;
@@ -384,69 +391,36 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3h(float* x, float* y, cons
                             const f16x8 v1 = __builtin_bit_cast(f16x8, vf[n % RING][1]);
                             // the three products of weight up to 2^-11, smallest first
                             m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u1, v0, m[t], 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            gap(q, 3 * n, JM);
-                            __builtin_amdgcn_sched_barrier(0);
+                            gap();
                             m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u0, v1, m[t], 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            gap(q, 3 * n + 1, JM);
-                            __builtin_amdgcn_sched_barrier(0);
+                            gap();
                             m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u0, v0, m[t], 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            gap(q, 3 * n + 2, JM);
+                            gap();
                         } else {
                             m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u0, v0, m[t], 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            gap(q, n, JM);
+                            gap();
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                // output transform: Y[i][j] += At[i][p] * At[j][q] * M (zero factors skipped at compile time)
-                const float cj0 = (q < 4) ? 1.0f : 0.0f;
-                const float cj1 = (q == 1) ? 1.0f : (q == 2 ? -1.0f : (q == 3 ? 2.0f : 0.0f));
-                const float cj2 = (q == 0) ? 0.0f : (q == 3 ? 4.0f : 1.0f);
+                if (corner) {
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    const int ci = (i == 0) ? (p < 4 ? 1 : 0)
-                                 : (i == 1) ? (p == 1 ? 1 : (p == 2 ? -1 : (p == 3 ? 2 : 0)))
-                                            : (p == 0 ? 0 : (p == 3 ? 4 : 1));
-                    if (corner) {
-                        if (i == ci_c) {
-#pragma unroll
-                            for (int t = 0; t < MT; t++) Y[ci_c][cj_c][t] = m[t];
-                        }
-                    } else if (ci != 0) {
-                        const float f0 = (float)ci * cj0, f1 = (float)ci * cj1, f2 = (float)ci * cj2;
-#pragma unroll
-                        for (int t = 0; t < MT; t++)
-#pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                if (JM & 1) Y[i][0][t][e] = fmaf(f0, m[t][e], Y[i][0][t][e]);
-                                if (JM & 2) Y[i][1][t][e] = fmaf(f1, m[t][e], Y[i][1][t][e]);
-                                if (JM & 4) Y[i][2][t][e] = fmaf(f2, m[t][e], Y[i][2][t][e]);
-                            }
-                    }
+                    for (int t = 0; t < MT; t++) Y[ci_c][cj_c][t] = m[t];
                 }
 #pragma unroll
                 for (int t = 0; t < MT; t++) vq[t] += NP * W::V_PART_U4 * 16;
-                if (pipe) {
-                    // rm[q] = the column formed in this stage's gaps (q is a run-time value inside the loop: selects, not indexing)
-                    if (JM == 1) rm[0] = rcur;
-                    else if (JM == 4) rm[4] = rcur;
-                    else if (NP == 1) {
-#pragma unroll
-                        for (int b = 1; b < 4; b++)
-#pragma unroll
-                            for (int e = 0; e < 4; e++) rm[b][e] = (q == b) ? rcur[e] : rm[b][e];
-                    }
-                }
                 __builtin_amdgcn_sched_barrier(0);
             };
-            stage(0, std::integral_constant<int, 1>{});
-#pragma unroll 1
-            for (int q = 1; q < 4; q++) stage(q, std::integral_constant<int, 7>{});
-            stage(4, std::integral_constant<int, 4>{});
+            stage(0, -1);
+            stage(1, 0);
+            stage(2, 1);
+            stage(3, 2);
+            stage(4, 3);
+            // the last stage's transform: tile-major, so the last tile's products (the stage's last MFMAs) are read
+            // behind the 2/3 of the operations that do not need them
+#pragma unroll
+            for (int n = 0; n < n_ops(p, 4); n++) tf_op(4, mb[0], n, -1, -1);
+            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();                                   // every wave has read this row of V (and, p < 4, the image for row p + 1's row half)
             W3H_STAMP(3 + 2 * (5 * cp + p));
             if (stage_next) {
@@ -454,7 +428,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3h(float* x, float* y, cons
                 __syncthreads();
             } else if (p < 4) {
                 if (p == 3 && cp == 0) load_img(2);            // in flight under the column half
-                finish_row(p + 1, W3H_PIPE != 0);
+                finish_row(p + 1, false);
             }
         }
     }
