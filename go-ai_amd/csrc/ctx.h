@@ -36,6 +36,10 @@ struct goai_ctx {
         for (void* p : allocs) (void)hipFree(p);
         for (void* p : host_allocs) (void)hipHostFree(p);
         host_allocs.clear();
+        for (auto& kv : train.graphs) (void)hipGraphExecDestroy(kv.second);
+        train.graphs.clear();
+        if (train.gstream) (void)hipStreamDestroy(train.gstream);
+        train.gstream = nullptr;
         for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
         prof_events.clear();
         allocs.clear();

@@ -37,6 +37,16 @@ struct Train {
     float *col_partial = nullptr, *bn_sums = nullptr, *wgrad_partial = nullptr, *conv_partial = nullptr;
     float *hz = nullptr, *dhz = nullptr, *f = nullptr, *df = nullptr;   // head: [M][2], [B][2P]
     float *h1 = nullptr, *dh1 = nullptr, *logits = nullptr, *dlogits = nullptr, *metrics = nullptr;
+    // The step as a HIP graph (round 3; GOAI_NO_TRAIN_GRAPH=1 at goai_train_init: plain launches): a step is ~55 launches per
+    // residual block and pass, all with arguments that only depend on the batch size, once the caller's arrays are copied
+    // to these staging buffers and the step's scalars (lr, weight decay, Adam's bias corrections) are read from `scal`.
+    bool graph_on = false;
+    uint8_t *in_states = nullptr, *in_next = nullptr;   // [max_batch][6][P]
+    float *in_wins = nullptr, *in_pi = nullptr;         // [max_batch], [max_batch][A]
+    float* scal = nullptr;                              // device: lr, weight decay, 1 - 0.9^t, sqrt(1 - 0.999^t)
+    float scal_host[4] = { 0.0f, 0.0f, 1.0f, 1.0f };
+    std::map<int, hipGraphExec_t> graphs;               // by batch size
+    hipStream_t gstream = nullptr;                      // the step's own stream when the context runs on the null stream (which cannot be captured)
 };
 
 int tr_conv0_fwd(int S, const uint8_t* states, const float* w, const float* b, float shift, float* z, int M, hipStream_t st);
@@ -59,6 +69,8 @@ int tr_linear_bwd(const float* dout, const float* f, const float* W, const float
                   int O, int J, hipStream_t st);
 int tr_critic_loss(const float* val, const float* wins, float* dval, float* metrics, int B, float weight, hipStream_t st);
 int tr_actor_loss(const float* logits, const float* pi, float* dlogits, float* metrics, int B, int A, hipStream_t st);
-int tr_adam(float* p, const float* g, float* m, float* v, long n, float lr, float wd, float bc1, float sqrt_bc2, hipStream_t st);
+int tr_fill(float* dst, long n, float v, hipStream_t st);
+// scal (device): lr, weight decay, bc1, sqrt(bc2)
+int tr_adam(float* p, const float* g, float* m, float* v, long n, const float* scal, hipStream_t st);
 
 }  // namespace goai

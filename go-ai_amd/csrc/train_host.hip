@@ -13,6 +13,7 @@
 #include <cmath>
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 
 #include "ctx.h"
 #include "goai_internal.h"
@@ -122,6 +123,16 @@ static int train_init_impl(goai_ctx* c, int kind, int layers, int max_batch)
         (rc = tr_alloc(c, &t.df, B * P * 2)) || (rc = tr_alloc(c, &t.h1, B * 256)) || (rc = tr_alloc(c, &t.dh1, B * 256)) ||
         (rc = tr_alloc(c, &t.logits, B * A)) || (rc = tr_alloc(c, &t.dlogits, B * A)) || (rc = tr_alloc(c, &t.metrics, 4)))
         return rc;
+    {
+        float* stage = nullptr;                       // the caller's arrays, copied here in front of the step's graph
+        const size_t st_floats = (B * 6 * P + 3) / 4;
+        if ((rc = tr_alloc(c, &stage, st_floats))) return rc;
+        t.in_states = reinterpret_cast<uint8_t*>(stage);
+        if ((rc = tr_alloc(c, &stage, st_floats))) return rc;
+        t.in_next = reinterpret_cast<uint8_t*>(stage);
+        if ((rc = tr_alloc(c, &t.in_wins, B)) || (rc = tr_alloc(c, &t.in_pi, B * A)) || (rc = tr_alloc(c, &t.scal, 4))) return rc;
+    }
+    t.graph_on = !getenv("GOAI_NO_TRAIN_GRAPH");
     GOAI_HIP_CHECK(hipStreamSynchronize(c->stream));
     t.steps = 0;
     t.ready = true;
@@ -348,18 +359,71 @@ int train_step(goai_ctx* c, const uint8_t* states, const uint8_t* next_states, c
     GOAI_REQUIRE(n >= 2 && n <= t.max_batch, "batch size must be in 2 .. max_batch");
     GOAI_REQUIRE(next_states && wins && metrics_host, "NULL array argument");
     GOAI_REQUIRE(t.kind == 1 || (states && pi), "the actor-critic step needs states and pi");
-    const Pass p{ c, t, c->S, c->P, c->A, n, n * c->P, c->stream };
-    const size_t img = (size_t)9 * 128 * 128;
-    GOAI_HIP_CHECK(hipMemsetAsync(t.grads, 0, t.n_params * sizeof(float), p.st));          // optimizer.zero_grad()
-    static const float nan4[4] = { NAN, NAN, NAN, NAN };
-    GOAI_HIP_CHECK(hipMemcpyAsync(t.metrics, nan4, sizeof(nan4), hipMemcpyHostToDevice, p.st));
-    for (int l = 1; l <= 2 * t.layers; l++)
-        TR_TRY(tr_relayout(p.par(trunk_names(l).conv + ".weight"), t.img_f + (size_t)(l - 1) * img, t.img_d + (size_t)(l - 1) * img, p.st));
-    TR_TRY(critic_pass(p, next_states, wins, t.kind == 0 ? 2.0f : 1.0f));
-    if (t.kind == 0) TR_TRY(actor_pass(p, states, pi));
+    hipStream_t st = c->stream;
+    if (t.graph_on && st == nullptr) {
+        // the null stream cannot be captured: the step runs on a stream of its own, behind everything queued so far
+        if (!t.gstream) GOAI_HIP_CHECK(hipStreamCreateWithFlags(&t.gstream, hipStreamNonBlocking));
+        GOAI_HIP_CHECK(hipStreamSynchronize(nullptr));
+        st = t.gstream;
+    }
+    const Pass p{ c, t, c->S, c->P, c->A, n, n * c->P, st };
     t.steps++;
     const double bc1 = 1.0 - std::pow(0.9, (double)t.steps), bc2 = 1.0 - std::pow(0.999, (double)t.steps);
-    TR_TRY(tr_adam(t.params, t.grads, t.adam_m, t.adam_v, (long)t.n_params, lr, weight_decay, (float)bc1, (float)std::sqrt(bc2), p.st));
+    t.scal_host[0] = lr;
+    t.scal_host[1] = weight_decay;
+    t.scal_host[2] = (float)bc1;
+    t.scal_host[3] = (float)std::sqrt(bc2);
+    GOAI_HIP_CHECK(hipMemcpyAsync(t.scal, t.scal_host, sizeof(t.scal_host), hipMemcpyHostToDevice, p.st));
+    // everything between the caller's arrays and the metrics: the same launches for every step of one batch size
+    auto body = [&](const uint8_t* st_in, const uint8_t* nx_in, const float* wins_in, const float* pi_in) -> int {
+        const size_t img = (size_t)9 * 128 * 128;
+        TR_TRY(tr_fill(t.grads, (long)t.n_params, 0.0f, p.st));                                  // optimizer.zero_grad()
+        TR_TRY(tr_fill(t.metrics, 4, NAN, p.st));
+        for (int l = 1; l <= 2 * t.layers; l++)
+            TR_TRY(tr_relayout(p.par(trunk_names(l).conv + ".weight"), t.img_f + (size_t)(l - 1) * img, t.img_d + (size_t)(l - 1) * img, p.st));
+        TR_TRY(critic_pass(p, nx_in, wins_in, t.kind == 0 ? 2.0f : 1.0f));
+        if (t.kind == 0) TR_TRY(actor_pass(p, st_in, pi_in));
+        return tr_adam(t.params, t.grads, t.adam_m, t.adam_v, (long)t.n_params, t.scal, p.st);
+    };
+    int rc = GOAI_OK;
+    if (t.graph_on) {
+        const size_t sb = (size_t)n * 6 * c->P;
+        if (t.kind == 0) {
+            GOAI_HIP_CHECK(hipMemcpyAsync(t.in_states, states, sb, hipMemcpyDeviceToDevice, p.st));
+            GOAI_HIP_CHECK(hipMemcpyAsync(t.in_pi, pi, (size_t)n * c->A * sizeof(float), hipMemcpyDeviceToDevice, p.st));
+        }
+        GOAI_HIP_CHECK(hipMemcpyAsync(t.in_next, next_states, sb, hipMemcpyDeviceToDevice, p.st));
+        GOAI_HIP_CHECK(hipMemcpyAsync(t.in_wins, wins, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, p.st));
+        auto it = t.graphs.find(n);
+        if (it == t.graphs.end()) {
+            // first step of this batch size: record the launches (nothing runs while the stream is capturing)
+            hipGraph_t graph = nullptr;
+            GOAI_HIP_CHECK(hipStreamBeginCapture(p.st, hipStreamCaptureModeThreadLocal));
+            rc = body(t.in_states, t.in_next, t.in_wins, t.in_pi);
+            const hipError_t ce = hipStreamEndCapture(p.st, &graph);
+            if (rc == GOAI_OK && ce != hipSuccess) {
+                set_error(std::string("hipStreamEndCapture (training step): ") + hipGetErrorString(ce));
+                rc = GOAI_ERR_HIP;
+            }
+            hipGraphExec_t exec = nullptr;
+            if (rc == GOAI_OK) {
+                const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                if (ie != hipSuccess) {
+                    set_error(std::string("hipGraphInstantiate (training step): ") + hipGetErrorString(ie));
+                    rc = GOAI_ERR_HIP;
+                }
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+            if (rc == GOAI_OK) it = t.graphs.emplace(n, exec).first;
+        }
+        if (rc == GOAI_OK) GOAI_HIP_CHECK(hipGraphLaunch(it->second, p.st));
+    } else
+        rc = body(states, next_states, wins, pi);
+    if (rc != GOAI_OK) {
+        t.steps--;
+        (void)hipStreamSynchronize(p.st);
+        return rc;
+    }
     GOAI_HIP_CHECK(hipMemcpyAsync(metrics_host, t.metrics, 4 * sizeof(float), hipMemcpyDeviceToHost, p.st));
     GOAI_HIP_CHECK(hipStreamSynchronize(p.st));
     return GOAI_OK;

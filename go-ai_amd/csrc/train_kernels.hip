@@ -477,18 +477,28 @@ __global__ __launch_bounds__(256) void k_tr_actor_loss(const float* __restrict__
 }
 
 // torch.optim.Adam with L2 weight decay folded into the gradient (betas 0.9 / 0.999, eps 1e-8); bc1 / bc2 are the
-// bias corrections 1 - beta^t of this step
+// bias corrections 1 - beta^t of this step.  The step's scalars come from device memory (scal: lr, weight decay, bc1,
+// sqrt(bc2)), so that the launch is the same from step to step (the step as a HIP graph, train_host.hip).
 __global__ __launch_bounds__(256) void k_tr_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                 float* __restrict__ v, long n, float lr, float wd, float bc1, float sqrt_bc2)
+                                                 float* __restrict__ v, long n, const float* __restrict__ scal)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const float lr = scal[0], wd = scal[1], bc1 = scal[2], sqrt_bc2 = scal[3];
     const float gi = fmaf(wd, p[i], g[i]);
     const float mi = 0.9f * m[i] + 0.1f * gi;
     const float vi = 0.999f * v[i] + 0.001f * gi * gi;
     m[i] = mi;
     v[i] = vi;
     p[i] -= (lr / bc1) * mi / (sqrtf(vi) / sqrt_bc2 + 1e-8f);
+}
+
+// dst[0..n) = v (the step's zero_grad and its NaN metrics as a launch: memset / host-memcpy nodes of a captured stream
+// gave garbage gradients from the second replay on, on this ROCm)
+__global__ __launch_bounds__(256) void k_tr_fill(float* __restrict__ dst, long n, float v)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = v;
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------------------
@@ -600,9 +610,14 @@ int tr_actor_loss(const float* logits, const float* pi, float* dlogits, float* m
     k_tr_actor_loss<<<1, 256, 0, st>>>(logits, pi, dlogits, metrics, B, A);
     TR_CHECK();
 }
-int tr_adam(float* p, const float* g, float* m, float* v, long n, float lr, float wd, float bc1, float sqrt_bc2, hipStream_t st)
+int tr_fill(float* dst, long n, float v, hipStream_t st)
 {
-    k_tr_adam<<<nblk(n), 256, 0, st>>>(p, g, m, v, n, lr, wd, bc1, sqrt_bc2);
+    k_tr_fill<<<nblk(n), 256, 0, st>>>(dst, n, v);
+    TR_CHECK();
+}
+int tr_adam(float* p, const float* g, float* m, float* v, long n, const float* scal, hipStream_t st)
+{
+    k_tr_adam<<<nblk(n), 256, 0, st>>>(p, g, m, v, n, scal);
     TR_CHECK();
 }
 

@@ -302,3 +302,36 @@ def test_three_steps_without_reloading_parameters(kind, size, n):
     for k in sshape:
         assert np.allclose(stats[k], sd[k].numpy(), rtol=1e-2, atol=1e-3), k
     c.close()
+
+
+@pytest.mark.parametrize("kind,size", [("ac", 9), ("val", 9), ("ac", 5)])
+def test_step_as_hip_graph_equals_plain_launches(kind, size, monkeypatch):
+    """Since round 3 goai_train_step replays one HIP graph per batch size (train_host.hip: the caller's arrays are copied to
+    staging buffers, lr / weight decay / Adam's bias corrections are read from device memory, so every launch has the same
+    arguments from step to step).  GOAI_NO_TRAIN_GRAPH=1 (read at goai_train_init) launches the same kernels one by one.
+    Same kernels, same order, same arguments: metrics, parameters, Adam moments and BatchNorm statistics are bit-identical
+    over four steps with two batch sizes (two graphs), a changing learning rate and fresh device arrays every step."""
+    sd = nn_ref.make_state_dict(kind, size, 23)
+    pshape, sshape = _shapes(sd)
+    outs = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("GOAI_NO_TRAIN_GRAPH", env)
+        else:
+            monkeypatch.delenv("GOAI_NO_TRAIN_GRAPH", raising=False)
+        rng = np.random.default_rng(9)
+        c = _ctx(kind, size, 32)
+        c.train_load(sd)
+        ms = []
+        for step, n in enumerate((32, 16, 32, 16)):
+            ms.append(c.train_step(*_random_batch(rng, size, n, kind), lr=1e-3 * (1 + step)))
+        outs.append((ms, c.train_export(pshape), c.train_export(pshape, c.TRAIN_ADAM_M), c.train_export(pshape, c.TRAIN_ADAM_V),
+                     c.train_export(sshape)))
+        c.close()
+    monkeypatch.delenv("GOAI_NO_TRAIN_GRAPH", raising=False)
+    assert outs[0][0] == outs[1][0]
+    for which in (1, 2, 3):
+        for k in pshape:
+            assert np.array_equal(outs[0][which][k], outs[1][which][k]), (which, k)
+    for k in sshape:
+        assert np.array_equal(outs[0][4][k], outs[1][4][k]), k
