@@ -420,10 +420,12 @@ def main():
     executed = executed_flop / launch_s / 1e12           # TFLOP/s the matrix pipe sustains
     achieved = conv_flop / launch_s / 1e12               # ALGORITHMIC: the convolutions' own flops per second (Winograd executes fewer)
 
-    # the transition side (north_star subsystem 1): k_transition over 262,144 boards (the size of one Q-search
-    # make_children step of 4096 games) taken from the games'
-    # current positions, HIP events on the launch stream; algorithmic bytes = 6P in + 6P out per board
-    tr = sp.profile_transition(262144)
+    # the transition side (north_star subsystem 1): k_transition over 1,048,576 boards per launch taken from the games'
+    # current positions, HIP events on the launch stream around 20 launches; algorithmic bytes = 6P in + 6P out per board.
+    # (Round 3: 262,144 boards per launch -- one Q-search make_children step of 4096 games -- take the kernel ~60 us at
+    # 9x9, less than the Python call that launches it: the events then timed the interpreter, 100 us per launch, where
+    # rocprofv3 shows 60 us of kernel (profiles/r03_c2_kernel_stats.csv).  Four times the boards keep the queue ahead.)
+    tr = sp.profile_transition(1048576)
 
     # the one collective of the run: gather per-rank results (utils.py:201-204's allreduces)
     from go_ai.sharding import gather_stats, reduce_stats

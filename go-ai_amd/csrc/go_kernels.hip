@@ -365,7 +365,12 @@ __global__ __launch_bounds__(64) void k_transition_staged(const uint8_t* __restr
     BB<S> nme = bb_zero<S>(), nopp = bb_zero<S>(), ninv = bb_zero<S>();
     uint32_t nflags = 0;
     int sign = 0;
+#ifdef GOAI_GO_DIAG_NO_RULES      // diagnostic build only (wrong results): the records' way in and out without the rules between them
+    const int rc = 0;
+    nme = opp; nopp = me; ninv = me; nflags = flags; sign = inv_at;
+#else
     const int rc = bits_next_state<S, 0>(me, opp, inv_at, flags, action, nme, nopp, ninv, nflags, sign);
+#endif
     const int np = 1 - player;
     const bool keep = canonical || np == 0;                     // the next mover's stones in plane 0
 #pragma unroll 1
