@@ -236,7 +236,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3h(float* x, float* y, cons
     u32x4 wf[2][NP];                                       // two half-stages of weights, used alternately
 #ifndef W3H_DIAG
 #define W3H_DIAG 0      // diagnostic builds only (wrong results): 1 no output transform, 2 every weight load reads stage 0 (L2-hot, same
-#endif                  // instructions), 4 no weight loads after the first, 8 no epilogue stores / residual loads
+#endif                  // instructions), 4 no weight loads after the first, 8 no residual loads, 16 no global stores in the epilogue
     auto load_b = [&](int stage, u32x4* b) {
         if ((W3H_DIAG & 4) && stage > 0) return;
         if (W3H_DIAG & 2) stage = 0;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3h(float* x, float* y, cons
 #pragma unroll
                 for (int i = 0; i < 3; i++)
 #pragma unroll
-                    for (int j = 0; j < 3; j++) rv[i][j] = *reinterpret_cast<const f32x4*>(&resid[base + (i * S + j) * 128]);
+                    for (int j = 0; j < 3; j++) rv[i][j] = (W3H_DIAG & 8) ? bv : *reinterpret_cast<const f32x4*>(&resid[base + (i * S + j) * 128]);
             }
 #pragma unroll
             for (int i = 0; i < 3; i++)
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3h(float* x, float* y, cons
                     if (R) v += rv[i][j];
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
-                    if (to_mem) *reinterpret_cast<f32x4*>(&out[base + (i * S + j) * 128]) = v;
+                    if (to_mem && (!(W3H_DIAG & 16) || v[0] == 12345.0f)) *reinterpret_cast<f32x4*>(&out[base + (i * S + j) * 128]) = v;
                     mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
                     if (to_lds) img_next[(icell + i * W::ROWC + j) * 8] = v;
                     if (to_heads) {

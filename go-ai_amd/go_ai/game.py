@@ -287,11 +287,13 @@ class BatchedSelfPlay:
             e1.synchronize()
             sec = e0.elapsed_time(e1) * 1e-3 / iters
             legal = float((status == 0).float().mean())
+            stones = float((states[:, 0] | states[:, 1]).sum()) / max(1, states.shape[0])
         nbytes = n_boards * 12 * P
         return {"bound": "hbm", "kernel": f"k_transition_staged<{self.size}>", "achieved": round(nbytes / sec / 1e9, 1),
                 "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / sec / 8e12, 4), "traffic": None,
                 "avg_launch_us": round(sec * 1e6, 2), "launches_timed": iters, "boards_per_launch": n_boards,
                 "algorithmic_bytes_per_board": 12 * P, "boards_per_s": round(n_boards / sec, 1), "legal_fraction": round(legal, 4),
+                "stones_per_board": round(stones, 1),
                 "note": "one board per lane as bit boards in registers, byte records staged through LDS in 16-byte lines; "
                         "bound by vector-ALU issue (pack / unpack of the uint8 planes and the flood fills), not by HBM "
                         "(DESIGN.md section 3; the one-board-per-wavefront kernel it replaces here: 0.083 at 65,536 boards)"}

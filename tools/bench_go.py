@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--sizes", type=int, nargs="+", default=[9, 19])
 ap.add_argument("--batch", type=int, default=1 << 18)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--moves", type=int, default=-1, help="moves played from the empty board to make the positions (default: P / 2)")
 args = ap.parse_args()
 
 
@@ -49,7 +50,7 @@ for size in args.sizes:
     P, A = size * size, size * size + 1
     n = args.batch
     c = Context(size)
-    st = positions(c, size, n, moves=P // 2)
+    st = positions(c, size, n, moves=P // 2 if args.moves < 0 else args.moves)
     stones = float((st[:, 0] | st[:, 1]).sum()) / n
     acts = c.sample_actions(c.uniform_policy(allow_pass=False), 7, 0)
     out, status = torch.empty_like(st), torch.empty(n, dtype=torch.int32, device="cuda")
