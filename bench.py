@@ -532,4 +532,17 @@ def main():
 
 
 if __name__ == "__main__":
+    # ONE JSON line on stdout, whatever the libraries print: RCCL writes a version banner to stdout when a communicator is made
+    # (torch's process group or goai_comm_init).  File descriptor 1 points at stderr for the run; the line goes to the real stdout.
+    sys.stdout.flush()
+    _real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    _print = print
+
+    def print(*a, **kw):      # noqa: A001 -- the JSON lines are the only print() calls without file=
+        if kw.get("file") is None:
+            kw["file"] = _real_stdout
+        _print(*a, **kw)
+
     main()
+    _real_stdout.flush()
