@@ -234,6 +234,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3h(float* x, float* y, cons
     constexpr unsigned W_STAGE_BYTES = 8 * 64 * NP * 16, W_CONV_BYTES = 100 * W_STAGE_BYTES;
     auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wconv), 0, W_CONV_BYTES, 0x00020000);
     u32x4 wf[2][NP];                                       // two half-stages of weights, used alternately
+#ifndef W3H_AH
+#define W3H_AH 2        // tile steps the V fragment reads run ahead of their MFMAs
+#endif
 #ifndef W3H_DIAG
 #define W3H_DIAG 0      // diagnostic builds only (wrong results): 1 no output transform, 2 every weight load reads stage 0 (L2-hot, same
 #endif                  // instructions), 4 no weight loads after the first, 8 no residual loads, 16 no global stores in the epilogue
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3h(float* x, float* y, cons
                 store_img(0);
                 load_img(3);
             }
-            constexpr int AH = 2, RING = AH + 1;
+            constexpr int AH = W3H_AH, RING = AH + 1;
             unsigned vq[MT];
             auto v_read = [&](int dq, int c, int t, uint4* v) {
                 const char* V = reinterpret_cast<const char*>(lds) + vq[t];
