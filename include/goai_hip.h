@@ -138,9 +138,10 @@ int goai_nn_init(goai_ctx* ctx, int net_kind, int n_blocks, int max_batch, int d
 int goai_nn_conv_algo(goai_ctx* ctx);
 
 /* How many of the trunk's 3x3 convolutions one kernel launch of this context runs (no reference
- * counterpart; a measurement aid like goai_nn_conv_algo): 2 * n_blocks when the F(3x3,3x3) kernel,
- * whose workgroups own whole boards, runs the whole residual trunk in one launch, else 1.
- * goai_profile_read counts launches. */
+ * counterpart; a measurement aid like goai_nn_conv_algo): 2 * n_blocks when a kernel whose
+ * workgroups own whole boards runs the whole residual trunk in one launch -- the F(3x3,3x3)
+ * kernels and, since round 3, every context of a split dtype (GOAI_DTYPE_F16X3 / _BF16X6 / _F16)
+ * on any board size -- else 1 (also with GOAI_NO_TRUNK_FUSION=1).  goai_profile_read counts launches. */
 int goai_nn_convs_per_launch(goai_ctx* ctx);
 
 /* Load a state_dict: `names[i]` are the reference's own keys ("main.0.weight",
@@ -360,7 +361,10 @@ int goai_train_reset_optimizer(goai_ctx* ctx);
  * its random symmetries (ac_net.py:69-71, models/__init__.py:119).  The value net takes
  * states = pi = NULL.  2 <= n <= max_batch.  metrics_host[4] (HOST): critic loss, critic
  * accuracy, actor loss, actor accuracy (NaN for the value net's last two).  Every reduction
- * runs in a fixed order: the same inputs give the same bits.  Synchronises the stream. */
+ * runs in a fixed order: the same inputs give the same bits.  Synchronises the stream.
+ * Since round 3 the step replays one HIP graph per batch size n (captured at the first step of
+ * that size; the arrays are copied to buffers of the context first, so they may be different
+ * allocations at every call); GOAI_NO_TRAIN_GRAPH=1 at goai_train_init: plain launches, same bits. */
 int goai_train_step(goai_ctx* ctx, const uint8_t* states, const uint8_t* next_states, const float* wins,
                     const float* pi, int n, float lr, float weight_decay, float* metrics_host);
 
