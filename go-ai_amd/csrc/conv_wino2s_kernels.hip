@@ -157,17 +157,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(float* x, float* y, cons
     // convolutions and spills them around the stages
     int tidv = tid;
     f32x4 ireg[W::NI];
+    // the workgroup's boards of the current input as a buffer: piece idx = tid + 512 i (cell idx / 8, 16-byte slot idx % 8) of chunk c sits
+    // at byte (idx / 8) * 512 + c * 128 + (idx % 8) * 16 -- one vector offset per thread, the rest a scalar offset; pieces beyond the
+    // boards that exist lie beyond the descriptor's range and read as zeros (no branches, no 64-bit addresses)
+    const int nb_boards = nboards - b_first < W::NBW ? nboards - b_first : W::NBW;
+    auto irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in) + (size_t)b_first * P * 128, 0, nb_boards * P * 512, 0x00020000);
     auto load_img = [&](int chunk) {
+        const unsigned voff = (unsigned)((tidv >> 3) * 512 + (tidv & 7) * 16);
 #pragma unroll
-        for (int i = 0; i < W::NI; i++) {
-            const int idx = tidv + i * 512;
-            const int cr = idx >> 3, slot = idx & 7;
-            const int board = b_first + cr / P;
-            f32x4 v = { 0.0f, 0.0f, 0.0f, 0.0f };
-            if (idx < W::NBW * P * 8 && board < nboards)
-                v = *reinterpret_cast<const f32x4*>(&in[((long)b_first * P + cr) * 128 + chunk * 32 + slot * 4]);
-            ireg[i] = v;
-        }
+        for (int i = 0; i < W::NI; i++)
+            ireg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, voff, chunk * 128 + i * 32768, 0));
     };
     auto store_img = [&]() {
 #pragma unroll
@@ -316,6 +315,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(float* x, float* y, cons
     tidv = tid;
     asm volatile("" : "+v"(tidv));
     W2S_STAMP(0);
+    if (k > 0) irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in) + (size_t)b_first * P * 128, 0, nb_boards * P * 512, 0x00020000);
     load_img(0);
     load_b(0, wf[0]);
     // V rows WT..ROWS-1 and the image's border cells are never written by the loop below: they stay zero (the V rows only
