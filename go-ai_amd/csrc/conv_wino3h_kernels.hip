@@ -135,17 +135,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3h(float* x, float* y, cons
     const bool tail_wave = wave == TAIL_WAVE;
 
     f32x4 ireg[W::NI];
+    // the workgroup's boards of the current input as a buffer (as conv_wino2s_kernels.hip): piece idx = tid + 512 i of chunk c at byte
+    // (idx / 8) * 512 + c * 128 + (idx % 8) * 16 = one vector offset per thread + a scalar offset; pieces of boards that do not
+    // exist lie beyond the descriptor's range and read as zeros
+    const int nb_boards = nboards - b_first < W::NBW ? nboards - b_first : W::NBW;
+    auto irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in) + (size_t)b_first * P * 128, 0, nb_boards * P * 512, 0x00020000);
     auto load_img_to = [&](int chunk, f32x4* reg) {
+        const unsigned voff = (unsigned)((tid >> 3) * 512 + (tid & 7) * 16);
 #pragma unroll
-        for (int i = 0; i < W::NI; i++) {
-            const int idx = tid + i * 512;
-            const int cr = idx >> 3, slot = idx & 7;
-            const int board = b_first + cr / P;
-            f32x4 v = { 0.0f, 0.0f, 0.0f, 0.0f };
-            if (idx < W::NBW * P * 8 && board < nboards)
-                v = *reinterpret_cast<const f32x4*>(&in[((long)b_first * P + cr) * 128 + chunk * 32 + slot * 4]);
-            reg[i] = v;
-        }
+        for (int i = 0; i < W::NI; i++)
+            reg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, voff, chunk * 128 + i * 32768, 0));
     };
     auto store_img_from = [&](int region, const f32x4* reg) {
 #pragma unroll
@@ -548,6 +547,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3h(float* x, float* y, cons
     }
     // next convolution of the launch: swap the buffers, step the weights
     if (k & 1) { in = x; out = y; resid = resid0; } else { in = y; out = x; resid = x; }
+    irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in) + (size_t)b_first * P * 128, 0, nb_boards * P * 512, 0x00020000);
     wconv += (size_t)100 * 8 * 64 * NP;
     wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wconv), 0, W_CONV_BYTES, 0x00020000);
     }
