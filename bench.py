@@ -321,6 +321,7 @@ def main():
                     help="also sum the per-rank results with the C-ABI's own RCCL all-reduce (goai_gather_stats) and "
                          "check it against the torch.distributed gather (always on when more than one rank runs)")
     ap.add_argument("--no-c-gather", action="store_true", help="N > 1: skip the C-ABI all-reduce cross-check")
+    ap.add_argument("--c-gather-timeout", type=float, default=120.0, help="seconds the C-ABI all-reduce leg may take before the line goes out without it")
     ap.add_argument("--no-exact-fp32", action="store_true",
                     help="skip the exact_fp32 sub-record (a few untimed-for-value steps of the same workload with --dtype f32)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -416,7 +417,11 @@ def main():
                             "peak_TBps": round(lds_peak / 1e12, 1), "frac": round(lds_bytes / launch_s / lds_peak, 4),
                             "note": "analytic LDS bytes of the launch at 128 B per clock and CU; SQ_LDS_IDX_ACTIVE measures 0.31 of the "
                                     "launch's CU cycles (profiles/r02_wino3s_ablation.txt).  Neither the matrix pipe nor LDS is what "
-                                    "this kernel waits for: its SIMDs are bound by instruction issue (a stage = 36 MFMAs at 17 cycles + ~56 packed fmas at 4.9 + reads and loads, and MFMAs and vector instructions do not overlap: tools/ubench/mfma_f16_valu.hip)"}}
+                                    "this kernel waits for: its SIMDs are bound by instruction issue.  Per SIMD a stage = 2 waves x 18 MFMAs "
+                                    "(16 cycles each = 576) and takes ~1,100 cycles with the fragment reads, weight loads and the output "
+                                    "transform's plain v_fmac_f32 in the MFMA gaps (two per gap issue for free, packed fp32 never overlaps: "
+                                    "tools/ubench/mfma_f16_valu2.hip / valu3.hip, profiles/r03_wino3h_notes.txt sections 1, 5, 6); the input "
+                                    "transforms between the stages (14.6 of a layer's 57 us) and the epilogue (11.5 us) run no MFMAs at all"}}
     executed = executed_flop / launch_s / 1e12           # TFLOP/s the matrix pipe sustains
     achieved = conv_flop / launch_s / 1e12               # ALGORITHMIC: the convolutions' own flops per second (Winograd executes fewer)
 
@@ -435,18 +440,38 @@ def main():
     tot = reduce_stats(per_rank)
     total_evals, t_max = tot["leaf_evals"], tot["seconds"]
 
-    c_gather = None
+    c_gather, c_gather_stuck = None, False
     if (args.c_gather or (world > 1 and not args.no_c_gather)) and len(sp.groups) == 1:
-        # the same sums through goai_gather_stats: rank 0's RCCL id goes round by torch.distributed, the all-reduce is the library's
+        # the same sums through goai_gather_stats: rank 0's RCCL id goes round by torch.distributed, the all-reduce is the library's.
+        # The leg runs beside the main thread with a time limit: the line's value and roofline are measured by now, and a communicator
+        # that will not form on some node (this path has run with one rank only so far) must not take them with it.
+        import threading
         ident = [sp.ctx.comm_unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(ident, src=0)
-        comm = sp.ctx.comm_init(ident[0], world, rank)
-        sums, extra = sp.ctx.gather_stats(comm, extra=[float(my_evals), float(st["games"])])
-        sp.ctx.comm_destroy(comm)
-        # (reported, not asserted: a rank that raised here would leave the others waiting in the next collective)
-        same = int(extra[0]) == int(total_evals) and int(extra[1]) == int(tot["games"])
-        c_gather = dict(sums, ranks=world, leaf_evals_timed=int(extra[0]), games=int(extra[1]), agrees_with_torch_gather=same)
+        box = {}
+
+        def leg():
+            try:
+                torch.cuda.set_device(local_rank)
+                comm = sp.ctx.comm_init(ident[0], world, rank)
+                sums, extra = sp.ctx.gather_stats(comm, extra=[float(my_evals), float(st["games"])])
+                sp.ctx.comm_destroy(comm)
+                box["ok"] = (sums, extra)
+            except Exception as e:      # noqa: BLE001 -- reported in the line
+                box["error"] = f"{type(e).__name__}: {e}"
+
+        th = threading.Thread(target=leg, daemon=True)
+        th.start()
+        th.join(args.c_gather_timeout)
+        if "ok" in box:
+            sums, extra = box["ok"]
+            # (reported, not asserted: a rank that raised here would leave the others waiting in the next collective)
+            same = int(extra[0]) == int(total_evals) and int(extra[1]) == int(tot["games"])
+            c_gather = dict(sums, ranks=world, leaf_evals_timed=int(extra[0]), games=int(extra[1]), agrees_with_torch_gather=same)
+        else:
+            c_gather_stuck = th.is_alive()
+            c_gather = {"ranks": world, "error": box.get("error", f"no answer within {args.c_gather_timeout:.0f} s (given up; the rest of the line does not depend on it)")}
 
     exact = None
     if rank == 0 and world == 1 and args.dtype != "f32" and not args.no_exact_fp32:
@@ -528,6 +553,10 @@ def main():
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 1)
         print(json.dumps(out), flush=True)
+    if c_gather_stuck:       # a thread is still inside RCCL: leave without the destructors that would wait for it
+        globals()["_real_stdout"].flush()
+        sys.stderr.flush()
+        os._exit(0)
     if world > 1:
         dist.destroy_process_group()
 
