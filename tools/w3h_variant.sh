@@ -1,0 +1,13 @@
+#!/bin/bash
+# Variant builds of the library with extra flags on conv_wino3h_kernels.hip -> go-ai_amd/csrc/build/diag/libgoai_w3h_<name>.so
+#   usage: tools/w3h_variant.sh <name> [hipcc flags...]
+set -e
+NAME=$1; shift
+cd "$(dirname "$0")/../go-ai_amd/csrc"
+make -j8 >/dev/null
+mkdir -p build/diag
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I../../include -mllvm -pragma-unroll-threshold=200000"
+OTHERS=$(ls build/*.o | grep -v conv_wino3h_kernels)
+/opt/rocm/bin/hipcc $FLAGS "$@" -c conv_wino3h_kernels.hip -o build/diag/w3h_$NAME.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o build/diag/libgoai_w3h_$NAME.so $OTHERS build/diag/w3h_$NAME.o
+rm build/diag/w3h_$NAME.o
