@@ -135,6 +135,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(float* x, float* y, cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int b_first = blockIdx.x * W::NBW;
+#ifdef W2S_SLEEP_ALL
+    // experiment: EVERY workgroup starts 0..3 x W2S_SLEEP_ALL sleep units late (conv_wino3h_kernels.hip's multi-round form)
+    for (int i = (blockIdx.x >> 3) % 4; i > 0; i--) __builtin_amdgcn_s_sleep(W2S_SLEEP_ALL);
+#endif
 #ifdef W2S_STAGGER
     // experiment: the first round's workgroups start W2S_STAGGER phases apart, so that the epilogues (the only HBM-heavy
     // part) of the workgroups resident at any time do not coincide

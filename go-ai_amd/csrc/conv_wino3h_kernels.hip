@@ -113,9 +113,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3h(float* x, float* y, cons
 #define W3H_START_GROUPS 16
 #define W3H_START_SLEEP 48
 #endif
-    // (the first 256 workgroups only = one per CU of an MI355X: the ones that start together; later ones start as those end)
-    if (n_convs > 1 && W3H_START_GROUPS > 1 && blockIdx.x < 256)
-        for (int i = (blockIdx.x >> 3) % W3H_START_GROUPS; i > 0; i--) __builtin_amdgcn_s_sleep(W3H_START_SLEEP);
+    // (that is for a launch of one workgroup per CU, the lock-step search's.  With more workgroups than CUs -- the Q search's
+    // 8192 -- every workgroup keeps round 2's four groups 3.9 us apart, which re-spreads the phases round after round: bench.py C3
+    // 0.207 of peak against 0.203 with sixteen groups or with the first round delayed only)
+    if (n_convs > 1 && W3H_START_GROUPS > 1) {
+        if (gridDim.x <= 256) for (int i = (blockIdx.x >> 3) % W3H_START_GROUPS; i > 0; i--) __builtin_amdgcn_s_sleep(W3H_START_SLEEP);
+        else for (int i = (blockIdx.x >> 3) % 4; i > 0; i--) __builtin_amdgcn_s_sleep(127);
+    }
     // everything zero: the borders of the image regions and the zero row of V stay zero for the whole launch
     for (int i = tid; i < 2 * W::REG_U4 + W::V_U4; i += 512) lds[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
     if (tid < 4) {
