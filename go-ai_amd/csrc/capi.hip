@@ -137,6 +137,12 @@ int goai_nn_conv_algo(goai_ctx* ctx)
     return ctx->net.wino_mode ? GOAI_CONV_WINOGRAD : GOAI_CONV_DIRECT;
 }
 
+int goai_mcts_steps_in_one_launch(goai_ctx* ctx)
+{
+    GOAI_REQUIRE(ctx, "ctx is NULL");
+    return ctx->steps_in_one_launch;
+}
+
 int goai_nn_convs_per_launch(goai_ctx* ctx)
 {
     GOAI_REQUIRE(ctx, "ctx is NULL");
@@ -462,7 +468,9 @@ int goai_profile_read(goai_ctx* ctx, double* conv_ms_total, int64_t* conv_launch
         total += ms;
     }
     *conv_ms_total = total;
-    *conv_launches = (int64_t)(ctx->prof_events.size() / 2);
+    // (a k_search_steps launch counts as the trunk passes it holds: conv_ms_total / conv_launches stays "per trunk pass")
+    *conv_launches = (int64_t)(ctx->prof_events.size() / 2) + ctx->prof_extra_passes;
+    ctx->prof_extra_passes = 0;
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     ctx->prof_events.clear();
     return GOAI_OK;

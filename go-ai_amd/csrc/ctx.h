@@ -19,6 +19,8 @@ struct goai_ctx {
     // optional per-launch timing of the dominant kernel (conv3x3) with HIP events on ctx->stream
     bool prof_enabled = false;
     std::vector<hipEvent_t> prof_events;   // start/stop pairs
+    int64_t prof_extra_passes = 0;         // trunk passes inside the timed launches beyond one per launch (k_search_steps)
+    int steps_in_one_launch = 0;           // the last goai_mcts_steps: trunk passes per k_search_steps launch, 0 = separate launches
     goai::Tree tree;
     goai::Train train;
     void* gather_buf = nullptr;   // device staging of goai_gather_stats (in allocs)

@@ -78,6 +78,9 @@ __host__ __device__ inline int meta_sign(uint64_t meta) { return (int)((meta >> 
 
 int launch_mcts_reset(int S, const Tree& t, const uint8_t* roots, hipStream_t st);
 int launch_mcts_select(int S, const Tree& t, uint8_t* leaf_states_out, hipStream_t st);
+int launch_search_steps(const Tree& t, float* x, float* y, const void* wt_split, const float* bias, int n_convs, int parts,
+                        const int* wexp, float amax_first, const HeadWeights& hw, float* hbuf, const void* w0_split,
+                        const float* b0, float shift, int n_steps, int spread, hipStream_t st);
 int launch_post_forward(int S, const Tree& t, const float* act, const HeadWeights& hw, const void* w0_split, const float* b0,
                         float shift, float* act0, hipStream_t st, bool act_is_h = false);
 int launch_mcts_backup(int S, const Tree& t, const float* pi_logits, const float* prior, const float* val,

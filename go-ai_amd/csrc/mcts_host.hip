@@ -213,11 +213,44 @@ int mcts_steps(goai_ctx* c, int n_steps)
     // separate kernels fill the chip better than a workgroup that is half idle in its middle phase (C4 / C5: -2 %).
     const bool small_batch = t.n_active <= 6 * c->net.n_cu;
     // (k_post_forward carries the <= 128-value backup only: long searches keep the separate launches)
+    c->steps_in_one_launch = 0;
     if (!no_fusion && small_batch && !t.vlog && n_steps >= 2 && !t.pending_select && t.n_active <= c->net.max_batch && c->net.w0_split) {
         float* x = nullptr;
         bool x_is_h = false;                    // x = the heads' 1x1 convolutions, formed by the trunk launch (nn_host.hip)
         if ((rc = mcts_select(c, nullptr))) return rc;
         if ((rc = nn_piece_conv0(c, t.leaf_planes, t.n_active))) return rc;
+        // 9x9 with the fp16 F(3x3,3x3) trunk and its heads in the last epilogue: the whole loop below in ONE launch
+        // (k_search_steps, mcts_kernels.hip: no workgroup ever waits for another).  OPT-IN, GOAI_STEPS_KERNEL=1: same bits, but
+        // measured SLOWER than the launches below (bench.py C2: 29.7 against 25.5 ms per move) -- a pass of the trunk takes what
+        // it takes with a start stagger (272 us), and the search's phases between two passes take 71 us instead of 22 when
+        // the rest of the chip is in its trunk passes at the time (dependent loads under load: heads 6.6 -> 30.8 us,
+        // backup + select 8.6 -> 17.3, first convolution 6.3 -> 22.5; tools/steps_stamps.py).
+        const Net& net = c->net;
+        const char* ns = getenv("GOAI_STEPS_KERNEL");
+        if (c->S == 9 && net.wino3h && net.split6 && net.trunk_fused && net.heads_in_trunk && net.layers > 0 && (t.n_active & 3) == 0 &&
+            t.n_active >= 4 && ns && ns[0] == '1') {
+            const char* sp = getenv("GOAI_STEPS_SPREAD");          // start spread in 64-clock units (a trunk pass of 3 blocks ~ 9000)
+            const int spread = sp ? atoi(sp) : 3000 * net.layers;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (c->prof_enabled) {
+                GOAI_HIP_CHECK(hipEventCreate(&e0));
+                GOAI_HIP_CHECK(hipEventCreate(&e1));
+                c->prof_events.push_back(e0);
+                c->prof_events.push_back(e1);
+                GOAI_HIP_CHECK(hipEventRecord(e0, c->stream));
+            }
+            rc = launch_search_steps(t, net.act[0], net.act[1], net.wt_split6, net.bt, 2 * net.layers, net.parts, net.wexp, net.amax0,
+                                     net.hw, net.hbuf, net.w0_split, net.b0, net.shift, n_steps, spread, c->stream);
+            if (e1) {
+                GOAI_HIP_CHECK(hipEventRecord(e1, c->stream));
+                c->prof_extra_passes += n_steps - 1;
+            }
+            if (rc) return rc;
+            t.steps_since_reset += n_steps - 1;     // their backups and the next steps' selects ran inside
+            c->steps_in_one_launch = n_steps;
+            if ((rc = nn_piece_heads(c, net.hbuf, true, t.pi_logits, t.val_logits, t.n_active))) return rc;
+            return mcts_backup(c, t.pi_logits, nullptr, t.val_logits, 1);
+        }
         for (int s = 0; s < n_steps; s++) {
             if ((rc = nn_piece_trunk(c, t.n_active, &x, &x_is_h))) return rc;
             if (s + 1 < n_steps) {

@@ -14,6 +14,7 @@
 #include "goai_internal.h"
 #include "mcts.h"
 #include "nn_groups.h"
+#include "conv_wino3h_body.h"
 
 namespace goai {
 // board_next_state (go_board.h) on the packed words themselves: the bit-board rules of go_bits.h with wave-uniform
@@ -421,6 +422,71 @@ __global__ __launch_bounds__(256) void k_post_forward(Tree t, const float* act, 
     PF_STAMP(4);
     conv0_group<S>(cl, t.leaf_planes, w0s, b0, shift, act0, n, b_first);
     PF_STAMP(5);
+}
+
+// THE WHOLE LOCK-STEP LOOP IN ONE LAUNCH (9x9, fp16 F(3x3,3x3) trunk; round 3): a 512-thread workgroup owns four games for
+// n_steps search steps -- trunk (conv_wino3h_body.inc: the statements of k_conv3x3_wino3h), then what k_post_forward does for
+// two games per 256 threads, here by the workgroup's two halves -- and never waits for another workgroup: no game depends on
+// another game.  What that buys (profiles/r03_wino3h_notes.txt section 9): with one launch per trunk pass every workgroup of
+// the chip is in the same phase at the same time, and the passes' memory phases (a convolution's residual reads and output
+// stores: 85 MB over the chip, 10 us at the full HBM rate) cost 35 us per pass, of which a start stagger recovers 15 at the
+// price of its own 22 us tail per launch; here the workgroups start spread over a whole pass ONCE per launch of n_steps
+// passes and stay spread.  Same device code as the separate kernels, same bits.  n_active must be a multiple of 4
+// (both halves of every workgroup make the same barrier calls).
+template <int NP>
+__global__ __launch_bounds__(512) void k_search_steps(Tree tree, float* x, float* y, const uint4* wt_all,
+                                                      const float* __restrict__ bias_all, int n_convs,
+                                                      const int* __restrict__ wexp_all, float amax_first, HeadWeights hw,
+                                                      float* hbuf, const uint4* __restrict__ w0s, const float* __restrict__ b0,
+                                                      float shift, int n_steps, int spread)
+{
+    __shared__ union { HeadsLds<9> h[2]; Conv0Lds<9> c[2]; } pl;      // 7.9 KB beside the trunk's 152.6
+    const int nboards = tree.n_active;
+    const float* resid0 = nullptr;
+    float* amax_io = nullptr;
+    const float* head_w = hw.conv_w;
+    const float* head_b = hw.conv_b;
+    float* head_out = hbuf;
+    // the workgroups' starts spread over `spread` sleep units of 64 clocks (a trunk pass), in the order of their index bits
+    // reversed over 8 bits so that neighbours (same XCD, same memory channels) are far apart
+    {
+        const unsigned r = __builtin_bitreverse32(blockIdx.x & 255u) >> 24;
+        for (int left = (int)(r * (unsigned)spread >> 8); left > 0; left -= 16) __builtin_amdgcn_s_sleep(16);
+    }
+#define SS_STAMP(i) if (step == 5) { PF_STAMP(i); }
+    for (int step = 0; step < n_steps; step++) {
+        SS_STAMP(0);
+        {
+#define W3H_WG blockIdx.x
+#include "conv_wino3h_body.inc"
+#undef W3H_WG
+        }
+        if (step + 1 == n_steps) break;
+        __threadfence_block();
+        __syncthreads();
+        SS_STAMP(1);
+        {
+            const int half = threadIdx.x >> 8, tid = threadIdx.x & 255, wave = tid >> 6;
+            const int bg = blockIdx.x * 4 + 2 * half;                  // this half's two games
+            heads_groups<9>(pl.h[half], hbuf, hw, 1, tree.pi_logits, tree.val_logits, nboards, bg, nboards, true, tid);
+            __threadfence_block();
+            __syncthreads();
+            SS_STAMP(2);
+            if (wave < 2 && bg + wave < nboards) {
+                backup_game<9>(tree, bg + wave, tree.pi_logits, nullptr, tree.val_logits, 1);
+                __threadfence_block();
+                select_game<9, true>(tree, bg + wave, nullptr, nullptr);
+            }
+            __threadfence_block();
+            __syncthreads();
+            SS_STAMP(3);
+            conv0_group<9>(pl.c[half], tree.leaf_planes, w0s, b0, shift, x, nboards, bg, tid);
+            __threadfence_block();
+            __syncthreads();
+            SS_STAMP(4);
+        }
+    }
+#undef SS_STAMP
 }
 
 // rootnode.get_visit_counts() / rootnode.prior_pi / rootnode.visits
@@ -950,6 +1016,26 @@ int launch_post_forward(int S_rt, const Tree& t, const float* act, const HeadWei
 {
     const int grid = (t.n_active + 1) / 2;
     GOAI_DISPATCH_SIZE(S_rt, k_post_forward<S><<<dim3(grid), dim3(256), 0, st>>>(t, act, hw, (const uint4*)w0_split, b0, shift, act0, act_is_h));
+    GOAI_HIP_CHECK(hipGetLastError());
+    return GOAI_OK;
+}
+// n_steps trunk passes with the search's work between them in one launch (k_search_steps): 9x9, n_active a multiple of 4,
+// split fp16 weights of the whole trunk (2 * layers convolutions), parts = 2 (f16x3) or 1 (f16)
+int launch_search_steps(const Tree& t, float* x, float* y, const void* wt_split, const float* bias, int n_convs, int parts,
+                        const int* wexp, float amax_first, const HeadWeights& hw, float* hbuf, const void* w0_split,
+                        const float* b0, float shift, int n_steps, int spread, hipStream_t st)
+{
+    if (t.n_active < 4 || (t.n_active & 3) || n_convs < 2 || (n_convs & 1) || (parts != 1 && parts != 2) || n_steps < 1) {
+        set_error("k_search_steps: 9x9, a multiple of four games, a whole residual trunk");
+        return GOAI_ERR_ARG;
+    }
+    const dim3 grid(t.n_active / 4), block(512);
+    if (parts == 2)
+        k_search_steps<2><<<grid, block, 0, st>>>(t, x, y, (const uint4*)wt_split, bias, n_convs, wexp, amax_first, hw, hbuf,
+                                                   (const uint4*)w0_split, b0, shift, n_steps, spread);
+    else
+        k_search_steps<1><<<grid, block, 0, st>>>(t, x, y, (const uint4*)wt_split, bias, n_convs, wexp, amax_first, hw, hbuf,
+                                                   (const uint4*)w0_split, b0, shift, n_steps, spread);
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }

@@ -32,16 +32,18 @@ struct Conv0Lds {
     uint4 xin[NB0 * Geom<S>::NPAD + 1];                            // [board][padded cell] 8 bf16; last = zero cell
 };
 
-// boards b_first .. b_first + NB0 - 1 by one 256-thread workgroup (all of its threads must call this)
+// boards b_first .. b_first + NB0 - 1 by one 256-thread workgroup (all of its threads must call this); tid_in >= 0: by the 256
+// threads that pass 0..255 here -- one half of k_search_steps' 512-thread workgroup, whose other half works on another `lds`
+// (the barriers inside are the whole workgroup's: both halves make the same calls)
 template <int S>
 __device__ __forceinline__ void conv0_group(Conv0Lds<S>& lds, const uint8_t* __restrict__ states, const uint4* __restrict__ w0s,
                                             const float* __restrict__ b0, float shift, float* __restrict__ out, int nboards,
-                                            int b_first)
+                                            int b_first, int tid_in = -1)
 {
     using G = Geom<S>;
     constexpr int CELLS = NB0 * G::P, TILES = (CELLS + 15) / 16;
     uint4* xin = lds.xin;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
 
     // weights: w0s[split][kstep][cout][kgroup] = 8 bf16
@@ -125,13 +127,14 @@ struct HeadsLds {
     float z[HB][4];
 };
 
-// groups of HB boards starting at b_begin, then every b_stride boards, by one 256-thread workgroup (all threads call it).
+// groups of HB boards starting at b_begin, then every b_stride boards, by one 256-thread workgroup (all threads call it;
+// tid_in as for conv0_group).
 // act_is_h: `act` holds the 1x1 convolutions already, [board][3][P] (the split F(3x3,3x3) trunk forms them in its last
 // epilogue), and they are only copied into LDS.
 template <int S>
 __device__ __forceinline__ void heads_groups(HeadsLds<S>& lds, const float* __restrict__ act, const HeadWeights& hw, int is_ac,
                                              float* __restrict__ pi_out, float* __restrict__ val_out, int nboards, int b_begin,
-                                             int b_stride, bool act_is_h = false)
+                                             int b_stride, bool act_is_h = false, int tid_in = -1)
 {
     using G = Geom<S>;
     constexpr int JG = HeadsLds<S>::JG;
@@ -139,7 +142,7 @@ __device__ __forceinline__ void heads_groups(HeadsLds<S>& lds, const float* __re
     auto& h = lds.h;
     auto& part = lds.part;
     auto& z = lds.z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seg = tid & 7;
     const int c_first = is_ac ? 0 : 2;
     f32x4 w[3][4];

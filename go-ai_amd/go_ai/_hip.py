@@ -52,6 +52,7 @@ _SIGNATURES = {
     "goai_mcts_policy_value": [c_void_p, c_double, c_int, c_void_p],
     "goai_mcts_run": [c_void_p, c_int],
     "goai_mcts_steps": [c_void_p, c_int],
+    "goai_mcts_steps_in_one_launch": [c_void_p],
     "goai_mcts_readout": [c_void_p, c_void_p, c_void_p, c_void_p],
     "goai_mcts_policy": [c_void_p, c_double, c_void_p],
     "goai_uniform_policy": [c_void_p, c_int, c_void_p],

@@ -377,6 +377,10 @@ class Context:
         self._bind()
         _hip.check(_hip.lib.goai_mcts_steps(self._h, int(n_steps)))
 
+    def mcts_steps_in_one_launch(self):
+        """Trunk passes per launch of the last mcts_steps (k_search_steps), 0 = separate launches."""
+        return int(_hip.lib.goai_mcts_steps_in_one_launch(self._h))
+
     def mcts_readout(self):
         self._bind()
         visits = torch.empty((self.n_games, self.A), dtype=torch.int32, device=self.device)

@@ -258,6 +258,12 @@ int goai_mcts_run(goai_ctx* ctx, int n_sims);
  * one group's tree kernels and kernel tails overlap the other group's convolutions. */
 int goai_mcts_steps(goai_ctx* ctx, int n_steps);
 
+/* How the last goai_mcts_steps of the context ran: k > 0 = as ONE launch of k trunk passes with the search's work between them
+ * (k_search_steps: opt-in by GOAI_STEPS_KERNEL=1 -- measured slower, DESIGN.md section 5 --; 9x9, GOAI_DTYPE_F16X3, a multiple of
+ * four games), 0 = as separate launches.  Same results either way, bit for bit.  No counterpart in the reference: it names the kernel that
+ * bench.py's roofline is about (goai_profile_read then counts every trunk pass of such a launch). */
+int goai_mcts_steps_in_one_launch(goai_ctx* ctx);
+
 /* rootnode.get_visit_counts() (tree.py:161-168) -> visit_counts [n_games][A] int32,
  * rootnode.prior_pi -> prior [n_games][A] float64, rootnode.visits -> root_visits [n_games];
  * any output may be NULL. */

@@ -224,3 +224,38 @@ def test_fused_step_equals_separate_launches(size, games, sims, layers):
         assert np.array_equal(a, b)
     assert outs[0][4] == outs[1][4] and outs[0][4]["errors"] == 0
     assert int(outs[0][2].min()) == sims + 1
+
+
+@pytest.mark.parametrize("games,sims,layers,dtype", [(64, 20, 3, "f16x3"), (8, 81, 3, "f16x3"), (1024, 12, 3, "f16x3"), (36, 9, 2, "f16"),
+                                                     (30, 9, 3, "f16x3")])
+def test_steps_in_one_launch_equal_separate_launches(games, sims, layers, dtype):
+    """goai_mcts_run's lock-step loop as ONE launch (k_search_steps: a workgroup owns four games for all steps, trunk passes
+    and the search's work between them in one kernel) against the same search with one launch per trunk pass
+    (the default; the one-launch form is opt-in, GOAI_STEPS_KERNEL=1: it measured slower): visit counts, priors, pi and the
+    search counters bit for bit; a game count that is not a multiple of four, and the reduced-precision tier (F(2x2,3x3) on
+    9x9), keep the separate launches."""
+    import os
+    from go_ai.engine import Context
+    roots = random_positions(9, games, seed=11 + games, max_moves=40, canonical=True).astype(np.uint8)
+    sd = nn_ref.make_state_dict("ac", 9, 7, layers=layers)
+    outs, how = [], []
+    for on in ("1", "0"):
+        os.environ["GOAI_STEPS_KERNEL"] = on
+        try:
+            c = Context(9, 0)
+            c.nn_init(Context.NET_AC, layers, games, dtype=Context.DTYPE_F16X3 if dtype == "f16x3" else Context.DTYPE_F16)
+            c.load_weights(sd)
+            c.mcts_init(games, sims)
+            c.mcts_reset(roots)
+            c.mcts_run(sims)
+            how.append(c.mcts_steps_in_one_launch())
+            visits, prior, root_visits = [t.cpu().numpy() for t in c.mcts_readout()]
+            outs.append((visits, prior, root_visits, c.mcts_policy(1.0).cpu().numpy(), c.mcts_counters()))
+            c.close()
+        finally:
+            os.environ.pop("GOAI_STEPS_KERNEL", None)
+    assert how == ([sims + 1, 0] if (dtype == "f16x3" and games % 4 == 0) else [0, 0]), how
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert np.array_equal(a, b)
+    assert outs[0][4] == outs[1][4] and outs[0][4]["errors"] == 0
+    assert int(outs[0][2].min()) == sims + 1
