@@ -61,8 +61,4 @@ __device__ __forceinline__ f32x4 h_fma4(float c, f32x4 a, f32x4 b)
 // quarter q of V row r sits at position q ^ w3h_vswz(r) (conv_wino3s_kernels.hip: fragment reads then touch all 64 banks)
 __device__ __forceinline__ int w3h_vswz(int row) { return (0 - (row >> 2)) & 3; }
 
-// Same launch contract as k_conv3x3_wino3s (n_convs convolutions in a row on the same boards): wexp_all[conv] = the
-// weights' scale exponent; amax_first > 0: bound of the first convolution's input, else amax_io[board]; amax_io != NULL:
-// receives the bound of the last convolution's output, per board; head_out != NULL: the last convolution feeds the
-// heads' three 1x1 convolutions and only those leave the workgroup.
 }  // namespace goai

@@ -118,26 +118,28 @@ __device__ __forceinline__ void conv0_group(Conv0Lds<S>& lds, const uint8_t* __r
 // by three xor-shuffles.
 // --------------------------------------------------------------------------------------
 constexpr int HB = 2;
+// (large batches of large boards: k_heads<S, 8> -- at 19x19 the two Linear layers' weights are 1.05 MB per workgroup, and 2048
+// workgroups of two boards re-read them from L2 for 270 us per 4096 boards; same sums per board in the same order, same bits)
 
-template <int S>
+template <int S, int HBT = HB>
 struct HeadsLds {
     static constexpr int JG = (256 / Geom<S>::A) > 0 ? (256 / Geom<S>::A) : 1;       // input slices of the actor Linear
-    float h[HB][3 * Geom<S>::P];  // [board][channel][cell]: act0, act1, crit (value net: crit only)
-    float part[JG][HB][Geom<S>::A];
-    float z[HB][4];
+    float h[HBT][3 * Geom<S>::P];  // [board][channel][cell]: act0, act1, crit (value net: crit only)
+    float part[JG][HBT][Geom<S>::A];
+    float z[HBT][4];
 };
 
 // groups of HB boards starting at b_begin, then every b_stride boards, by one 256-thread workgroup (all threads call it;
 // tid_in as for conv0_group).
 // act_is_h: `act` holds the 1x1 convolutions already, [board][3][P] (the split F(3x3,3x3) trunk forms them in its last
 // epilogue), and they are only copied into LDS.
-template <int S>
-__device__ __forceinline__ void heads_groups(HeadsLds<S>& lds, const float* __restrict__ act, const HeadWeights& hw, int is_ac,
+template <int S, int HBT = HB>
+__device__ __forceinline__ void heads_groups(HeadsLds<S, HBT>& lds, const float* __restrict__ act, const HeadWeights& hw, int is_ac,
                                              float* __restrict__ pi_out, float* __restrict__ val_out, int nboards, int b_begin,
                                              int b_stride, bool act_is_h = false, int tid_in = -1)
 {
     using G = Geom<S>;
-    constexpr int JG = HeadsLds<S>::JG;
+    constexpr int JG = HeadsLds<S, HBT>::JG;
     constexpr int JLEN = (2 * G::P + JG - 1) / JG;
     auto& h = lds.h;
     auto& part = lds.part;
@@ -155,7 +157,7 @@ __device__ __forceinline__ void heads_groups(HeadsLds<S>& lds, const float* __re
     const float cb[3] = { hw.conv_b[0], hw.conv_b[1], hw.conv_b[2] };
 
     for (int b0 = b_begin; b0 < nboards; b0 += b_stride) {
-        const int nb = min(HB, nboards - b0);
+        const int nb = min(HBT, nboards - b0);
         __syncthreads();
         // ---- 1x1 convolutions -> h ----
         // All of a thread's activation loads (64 B per item, up to NLD items in flight) are issued before the first
@@ -163,7 +165,7 @@ __device__ __forceinline__ void heads_groups(HeadsLds<S>& lds, const float* __re
         const int items = act_is_h ? 0 : nb * G::P * 8;
         if (act_is_h)
             for (int i = tid; i < nb * 3 * G::P; i += 256) (&h[0][0])[i] = act[(size_t)b0 * 3 * G::P + i];
-        constexpr int NIT = (HB * G::P * 8 + 255) / 256, NLD = NIT < 6 ? NIT : 6;
+        constexpr int NIT = (HBT * G::P * 8 + 255) / 256, NLD = NIT < 6 ? NIT : 6;
         for (int it0 = 0; it0 < items; it0 += 256 * NLD) {
             f32x4 xs[NLD][4];
 #pragma unroll
@@ -212,17 +214,17 @@ __device__ __forceinline__ void heads_groups(HeadsLds<S>& lds, const float* __re
             for (int o = tid; o < JG * G::A; o += 256) {
                 const int jg = o / G::A, a = o - jg * G::A;
                 const int j0 = jg * JLEN, j1 = min(2 * G::P, j0 + JLEN);
-                float sum[HB];
+                float sum[HBT];
 #pragma unroll
-                for (int b = 0; b < HB; b++) sum[b] = 0.0f;
+                for (int b = 0; b < HBT; b++) sum[b] = 0.0f;
 #pragma unroll 18
                 for (int j = j0; j < j1; j++) {
                     const float wv = hw.act_lin_wt[(size_t)j * G::A + a];
 #pragma unroll
-                    for (int b = 0; b < HB; b++) sum[b] = fmaf(wv, h[b][j], sum[b]);
+                    for (int b = 0; b < HBT; b++) sum[b] = fmaf(wv, h[b][j], sum[b]);
                 }
 #pragma unroll
-                for (int b = 0; b < HB; b++) part[jg][b][a] = sum[b];
+                for (int b = 0; b < HBT; b++) part[jg][b][a] = sum[b];
             }
             __syncthreads();
             for (int o = tid; o < nb * G::A; o += 256) {
@@ -235,19 +237,19 @@ __device__ __forceinline__ void heads_groups(HeadsLds<S>& lds, const float* __re
         }
         // ---- critic: Linear(P -> 256) ReLU Linear(256 -> 1) ----
         {
-            float sum[HB];
+            float sum[HBT];
             const float bias = hw.crit_b1[tid];
 #pragma unroll
-            for (int b = 0; b < HB; b++) sum[b] = bias;
+            for (int b = 0; b < HBT; b++) sum[b] = bias;
 #pragma unroll 27
             for (int p = 0; p < G::P; p++) {
                 const float wv = hw.crit_w1t[p * 256 + tid];
 #pragma unroll
-                for (int b = 0; b < HB; b++) sum[b] = fmaf(wv, h[b][2 * G::P + p], sum[b]);
+                for (int b = 0; b < HBT; b++) sum[b] = fmaf(wv, h[b][2 * G::P + p], sum[b]);
             }
             const float w2 = hw.crit_w2[tid];
 #pragma unroll
-            for (int b = 0; b < HB; b++) {
+            for (int b = 0; b < HBT; b++) {
                 float v = fmaxf(sum[b], 0.0f) * w2;
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);

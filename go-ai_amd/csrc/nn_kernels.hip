@@ -74,12 +74,12 @@ __global__ __launch_bounds__(256) void k_conv0_mfma(const uint8_t* __restrict__ 
     conv0_group<S>(lds, states, w0s, b0, shift, out, nboards, blockIdx.x * NB0);
 }
 
-template <int S>
+template <int S, int HBT>
 __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ act, HeadWeights hw, int is_ac,
                                                float* __restrict__ pi_out, float* __restrict__ val_out, int nboards, bool act_is_h)
 {
-    __shared__ HeadsLds<S> lds;
-    heads_groups<S>(lds, act, hw, is_ac, pi_out, val_out, nboards, blockIdx.x * HB, gridDim.x * HB, act_is_h);
+    __shared__ HeadsLds<S, HBT> lds;
+    heads_groups<S, HBT>(lds, act, hw, is_ac, pi_out, val_out, nboards, blockIdx.x * HBT, gridDim.x * HBT, act_is_h);
 }
 
 // --------------------------------------------------------------------------------------
@@ -162,9 +162,17 @@ int launch_conv0(int S_rt, const uint8_t* states, const float* w0, const void* w
 int launch_heads(int S_rt, const float* act, const HeadWeights& hw, int is_ac, float* pi, float* val, int nboards,
                  hipStream_t st, bool act_is_h)
 {
-    int groups = (nboards + HB - 1) / HB;
+    // eight boards per workgroup where the Linear weights are large and there are workgroups enough (nn_groups.h)
+    const char* hb = getenv("GOAI_HEADS_HB");
+    const bool wide = hb ? hb[0] == '8' : (S_rt >= 13 && nboards >= 2048);
+    const int per = wide ? 8 : HB;
+    int groups = (nboards + per - 1) / per;
     int grid = groups < 8192 ? groups : 8192;
-    GOAI_DISPATCH_SIZE(S_rt, k_heads<S><<<dim3(grid), dim3(256), 0, st>>>(act, hw, is_ac, pi, val, nboards, act_is_h));
+    if (wide) {
+        GOAI_DISPATCH_SIZE(S_rt, (k_heads<S, 8><<<dim3(grid), dim3(256), 0, st>>>(act, hw, is_ac, pi, val, nboards, act_is_h)));
+    } else {
+        GOAI_DISPATCH_SIZE(S_rt, (k_heads<S, HB><<<dim3(grid), dim3(256), 0, st>>>(act, hw, is_ac, pi, val, nboards, act_is_h)));
+    }
     GOAI_HIP_CHECK(hipGetLastError());
     return GOAI_OK;
 }
