@@ -26,22 +26,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // --------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int NB0 = 2;      // boards per workgroup (measured at 1024 boards of 9x9: 4 -> 13.4 us, 2 -> 11.7 us, 1 -> 13.2 us)
+// (large batches: k_conv0_mfma<S, 8> -- a workgroup's weights are 55 KB from L2, once per NBT boards)
 
-template <int S>
+template <int S, int NBT = NB0>
 struct Conv0Lds {
-    uint4 xin[NB0 * Geom<S>::NPAD + 1];                            // [board][padded cell] 8 bf16; last = zero cell
+    uint4 xin[NBT * Geom<S>::NPAD + 1];                            // [board][padded cell] 8 bf16; last = zero cell
 };
 
-// boards b_first .. b_first + NB0 - 1 by one 256-thread workgroup (all of its threads must call this); tid_in >= 0: by the 256
+// boards b_first .. b_first + NBT - 1 by one 256-thread workgroup (all of its threads must call this); tid_in >= 0: by the 256
 // threads that pass 0..255 here -- one half of k_search_steps' 512-thread workgroup, whose other half works on another `lds`
 // (the barriers inside are the whole workgroup's: both halves make the same calls)
-template <int S>
-__device__ __forceinline__ void conv0_group(Conv0Lds<S>& lds, const uint8_t* __restrict__ states, const uint4* __restrict__ w0s,
+template <int S, int NBT = NB0>
+__device__ __forceinline__ void conv0_group(Conv0Lds<S, NBT>& lds, const uint8_t* __restrict__ states, const uint4* __restrict__ w0s,
                                             const float* __restrict__ b0, float shift, float* __restrict__ out, int nboards,
                                             int b_first, int tid_in = -1)
 {
     using G = Geom<S>;
-    constexpr int CELLS = NB0 * G::P, TILES = (CELLS + 15) / 16;
+    constexpr int CELLS = NBT * G::P, TILES = (CELLS + 15) / 16;
     uint4* xin = lds.xin;
     const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
@@ -59,7 +60,7 @@ __device__ __forceinline__ void conv0_group(Conv0Lds<S>& lds, const uint8_t* __r
 #pragma unroll
     for (int ct = 0; ct < 2; ct++) bias[ct] = *reinterpret_cast<const f32x4*>(&b0[wave * 32 + ct * 16 + 4 * lq]);
 
-    for (int i = tid; i < NB0 * G::NPAD + 1; i += 256) xin[i] = uint4{ 0u, 0u, 0u, 0u };
+    for (int i = tid; i < NBT * G::NPAD + 1; i += 256) xin[i] = uint4{ 0u, 0u, 0u, 0u };
     __syncthreads();
     // planes -> bf16 (x - shift): one thread per (board, cell), 6 channels packed into 16 bytes
     const uint32_t one = __builtin_bit_cast(uint16_t, (__bf16)(1.0f - shift)), zer = __builtin_bit_cast(uint16_t, (__bf16)(0.0f - shift));
@@ -84,7 +85,7 @@ __device__ __forceinline__ void conv0_group(Conv0Lds<S>& lds, const uint8_t* __r
 #pragma unroll
         for (int ks = 0; ks < 3; ks++) {
             const int tap = ks * 4 + lq;
-            const int qq = (on && tap < 9) ? q + (tap / 3 - 1) * G::PS + (tap % 3 - 1) : NB0 * G::NPAD;
+            const int qq = (on && tap < 9) ? q + (tap / 3 - 1) * G::PS + (tap % 3 - 1) : NBT * G::NPAD;
             const bf16x8 xb = __builtin_bit_cast(bf16x8, xin[qq]);
 #pragma unroll
             for (int ct = 0; ct < 2; ct++)

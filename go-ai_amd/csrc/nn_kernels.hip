@@ -65,13 +65,13 @@ __global__ __launch_bounds__(256) void k_conv0(const uint8_t* __restrict__ state
     }
 }
 
-template <int S>
+template <int S, int NBT>
 __global__ __launch_bounds__(256) void k_conv0_mfma(const uint8_t* __restrict__ states, const uint4* __restrict__ w0s,
                                                     const float* __restrict__ b0, float shift,
                                                     float* __restrict__ out, int nboards)
 {
-    __shared__ Conv0Lds<S> lds;
-    conv0_group<S>(lds, states, w0s, b0, shift, out, nboards, blockIdx.x * NB0);
+    __shared__ Conv0Lds<S, NBT> lds;
+    conv0_group<S, NBT>(lds, states, w0s, b0, shift, out, nboards, blockIdx.x * NBT);
 }
 
 template <int S, int HBT>
@@ -147,9 +147,16 @@ int launch_conv0(int S_rt, const uint8_t* states, const float* w0, const void* w
                  float* out, int nboards, hipStream_t st)
 {
     if (w0_split) {
-        const int grid = (nboards + NB0 - 1) / NB0;
-        GOAI_DISPATCH_SIZE(S_rt, k_conv0_mfma<S><<<dim3(grid), dim3(256), 0, st>>>(
-                                     states, (const uint4*)w0_split, b0, shift, out, nboards));
+        // eight boards per workgroup when there are workgroups enough (nn_groups.h)
+        const char* nb = getenv("GOAI_CONV0_NB");
+        const bool wide = nb ? nb[0] == '8' : (S_rt >= 13 && nboards >= 4096);     // (9x9, 32,768 boards: no difference)
+        const int per = wide ? 8 : NB0;
+        const int grid = (nboards + per - 1) / per;
+        if (wide) {
+            GOAI_DISPATCH_SIZE(S_rt, (k_conv0_mfma<S, 8><<<dim3(grid), dim3(256), 0, st>>>(states, (const uint4*)w0_split, b0, shift, out, nboards)));
+        } else {
+            GOAI_DISPATCH_SIZE(S_rt, (k_conv0_mfma<S, NB0><<<dim3(grid), dim3(256), 0, st>>>(states, (const uint4*)w0_split, b0, shift, out, nboards)));
+        }
         GOAI_HIP_CHECK(hipGetLastError());
         return GOAI_OK;
     }
