@@ -265,7 +265,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(float* x, float* y, cons
     const unsigned wlane = (wave * (64 * NP) + lane) * 16;
     const uint4* wt = wt_all;
     auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wt), 0, 64 * W_STAGE_BYTES, 0x00020000);
-    u32x4 wf[2][NP];
+#ifndef W2S_WAHEAD
+#define W2S_WAHEAD 2    // stages the weight loads run ahead of their MFMAs (2: a ring of three buffers, as conv_wino3h_body.inc; 1 -> 2: C4 launch 5.93 -> 5.86 ms, C5 19.63 -> 19.51)
+#endif
+    // (W2S_WAHEAD == 2: a chunk is a sequence of 16 stages -- position 4 p + q -- plus two idle positions, 18 = 0 mod 3, so that the
+    // ring's phase is the same in every chunk; the stage at position pos uses buffer pos % 3 and requests position pos + 2)
+    constexpr int WRING = W2S_WAHEAD + 1;
+    u32x4 wf[WRING][NP];
     auto load_b = [&](int stage, u32x4* b) {
 #pragma unroll
         for (int r = 0; r < NP; r++)
@@ -322,6 +328,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(float* x, float* y, cons
     if (k > 0) irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in) + (size_t)b_first * P * 128, 0, nb_boards * P * 512, 0x00020000);
     load_img(0);
     load_b(0, wf[0]);
+    if (W2S_WAHEAD == 2) load_b(1, wf[1]);
     // V rows WT..ROWS-1 and the image's border cells are never written by the loop below: they stay zero (the V rows only
     // reach accumulator columns that are never stored); the epilogue's exchange area lies over both, hence once per convolution
     for (int i = tid; i < W::IMG_U4 + W::V_U4; i += 512) lds[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
@@ -357,8 +364,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(float* x, float* y, cons
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 {
-                    const int qq = q & 1;
+                    const int pos = p * 4 + q;
+                    const int qq = W2S_WAHEAD == 2 ? pos % 3 : (q & 1);
                     const int s = chunk * 16 + p * 4 + q;
+                    if (W2S_WAHEAD == 2) {
+                        if (pos + 2 < 16 && !(W2S_DIAG & 16)) load_b(s + 2, wf[(pos + 2) % 3]);
+                    } else
                     if (!(W2S_DIAG & 16)) load_b(s + 1 < 64 ? s + 1 : 63, wf[(qq + 1) & 1]);   // unconditional: the wait counts stay exact
 #pragma unroll
                     for (int t = 0; t < MT; t++) {
@@ -416,6 +427,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino2s(float* x, float* y, cons
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15");
             out_tf(p, 3, MT - 1, mr[(4 * MT - 1) % 3], 1, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (W2S_WAHEAD == 2 && p == 3 && !(W2S_DIAG & 16)) {      // the chunk's two idle positions: the next chunk's first two stages
+                load_b(chunk * 16 + 16 < 64 ? chunk * 16 + 16 : 63, wf[0]);
+                load_b(chunk * 16 + 17 < 64 ? chunk * 16 + 17 : 63, wf[1]);
+            }
             W2S_STAMP(3 + 2 * (4 * chunk + p));
         }
     }
