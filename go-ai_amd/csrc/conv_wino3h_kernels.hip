@@ -33,21 +33,26 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino3h(float* x, float* y, cons
                                                         const float* __restrict__ head_w, const float* __restrict__ head_b,
                                                         float* __restrict__ head_out)
 {
-    // workgroups of a several-convolution launch start in sixteen groups 1.5 us apart, so that their memory phases do not all
+    // workgroups of a several-convolution launch start in sixteen groups 0.37 us apart, so that their memory phases do not all
     // fall into the same microseconds: a convolution's residual reads and output stores are 85 MB over the chip, 10 us at the
-    // full HBM rate if every workgroup is in its epilogue at once (conv_wino3s_kernels.hip; profiles/r02_wino3s_ablation.txt;
-    // round 3, bench.py C2 launch: no groups 289 us, 2 x 3.9 us 284, 4 x 3.9 us -- round 2's -- 277, 8 x 2.9 us 274.3,
-    // 16 x 1.5 us 273.9: profiles/r03_wino3h_notes.txt section 9)
+    // full HBM rate if every workgroup is in its epilogue at once (conv_wino3s_kernels.hip; profiles/r02_wino3s_ablation.txt).
+    // bench.py C2 launch, round 3 (profiles/r03_wino3h_notes.txt sections 9, 12): with the weight loads ONE half-stage ahead
+    // no groups 289 us, round 2's 4 x 3.9 us 277, 16 x 1.5 us 273.9; with them TWO ahead (W3H_WAHEAD) the exposed weight
+    // latency no longer multiplies the contention: no groups 262.5 us, 16 x 1.5 us 270, 16 x 0.5 us 258.9, 16 x 0.37 us 258.2
 #ifndef W3H_START_GROUPS
 #define W3H_START_GROUPS 16
-#define W3H_START_SLEEP 48
+#define W3H_START_SLEEP 12
+#endif
+#ifndef W3H_BIG_SLEEP
+#define W3H_BIG_SLEEP 0
 #endif
     // (that is for a launch of one workgroup per CU, the lock-step search's.  With more workgroups than CUs -- the Q search's
-    // 8192 -- every workgroup keeps round 2's four groups 3.9 us apart, which re-spreads the phases round after round: bench.py C3
-    // 0.207 of peak against 0.203 with sixteen groups or with the first round delayed only)
+    // 8192 -- no workgroup is delayed: while the weight loads ran one half-stage ahead, round 2's four groups 3.9 us apart for
+    // every workgroup were worth 2 % there (W3H_BIG_SLEEP = 127); with them two ahead they cost 8 %: bench.py C3 0.196 of peak
+    // with the delays, 0.213 without)
     if (n_convs > 1 && W3H_START_GROUPS > 1) {
         if (gridDim.x <= 256) for (int i = (blockIdx.x >> 3) % W3H_START_GROUPS; i > 0; i--) __builtin_amdgcn_s_sleep(W3H_START_SLEEP);
-        else for (int i = (blockIdx.x >> 3) % 4; i > 0; i--) __builtin_amdgcn_s_sleep(127);
+        else if (W3H_BIG_SLEEP > 0) for (int i = (blockIdx.x >> 3) % 4; i > 0; i--) __builtin_amdgcn_s_sleep(W3H_BIG_SLEEP);
     }
 #define W3H_WG blockIdx.x
 #include "conv_wino3h_body.inc"
